@@ -1,0 +1,398 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container (where /root/reference is
+mounted), never on the GPU box.  Nothing from the reference is copied into the repo:
+its modules are loaded from where they lie (SURVEY.md 8c recipes O1-O4), executed on
+seeded synthetic inputs, and only the inputs and outputs are written out.
+
+  O1  W12m/bresenham.py   loaded as-is (pure Python).
+  O2  W12m/mapping.py     loaded as-is with empty stub modules for rospy / nav_msgs.
+  O3  W12f/icp-fhb.py     loaded as-is with ``np.int = int`` (cross-check only; its
+                          reflection branch indexes Vt[2,:] and is never exercised).
+  O4  W12m/icp.py         Python-2 print statements rewritten IN MEMORY by lib2to3's
+                          fix_print, then exec'd with stubs for rospy / tf / *_msgs.
+      W12m/slam_ekf.py    same treatment, used only for its glue methods
+                          laserToNumpy / calc_odometry / T2u / u2T (EKF and landmark
+                          extraction are stubbed: out of scope).
+
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,g2,g3,g4]
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import hashlib
+import importlib
+import importlib.util
+import io
+import os
+import sys
+import time
+import types
+import zlib
+
+import numpy as np
+
+REF = "/root/reference"
+W12M = os.path.join(REF, "W12_LiDAR SLAM", "w12-mapping", "course_agv_slam", "scripts")
+W12F = os.path.join(REF, "W12_LiDAR SLAM", "w12-ekf-slam-final", "course_agv_slam", "scripts")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+syn = importlib.import_module("a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd.synthetic")
+
+PARAMS = {"/slam/map_width": 20, "/slam/map_height": 20, "/slam/map_resolution": 0.1}
+
+
+# ----------------------------------------------------------------------------
+# reference loaders
+# ----------------------------------------------------------------------------
+def _install_stubs():
+    if not hasattr(np, "int"):
+        np.int = int  # removed in NumPy 1.24; the reference predates that
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return _Anything()
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+    class _Time:
+        def now(self=None):
+            return 0.0
+
+    def get_param(name, default=None):
+        return PARAMS.get(name, default)
+
+    mod("rospy", get_param=get_param, Publisher=_Anything, Subscriber=_Anything, Time=_Time,
+        init_node=lambda *a, **k: None, spin=lambda: None, sleep=lambda *a: None, get_time=time.time)
+    tfm = mod("tf", TransformBroadcaster=_Anything)
+    tfm.transformations = types.SimpleNamespace(quaternion_from_euler=lambda r, p, y: (0.0, 0.0, np.sin(y / 2), np.cos(y / 2)))
+    for pkg, names in (("sensor_msgs", ("LaserScan",)), ("nav_msgs", ("Odometry", "OccupancyGrid")),
+                       ("geometry_msgs", ("TransformStamped",)), ("visualization_msgs", ("MarkerArray", "Marker"))):
+        mod(pkg)
+        mod(pkg + ".msg", **{n: _Anything for n in names})
+    mod("nav_msgs.srv", GetMap=_Anything)
+    # out-of-scope collaborators of slam_ekf.py
+    mod("ekf_lm", EKF=_Anything, STATE_SIZE=3)
+    mod("extraction", LandMarkSet=_Anything, Extraction=_Anything)
+
+
+def _load_asis(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def _load_py2(name, path):
+    from lib2to3.refactor import RefactoringTool
+    text = open(path).read()
+    tree = RefactoringTool(["lib2to3.fixes.fix_print"]).refactor_string(text + "\n", path)
+    m = types.ModuleType(name)
+    m.__file__ = path
+    sys.modules[name] = m
+    exec(compile(str(tree), path, "exec"), m.__dict__)
+    return m
+
+
+def load_reference():
+    _install_stubs()
+    sys.path.insert(0, W12M)
+    ref = types.SimpleNamespace()
+    ref.bresenham = _load_asis("bresenham", os.path.join(W12M, "bresenham.py"))     # O1
+    ref.mapping = _load_asis("mapping", os.path.join(W12M, "mapping.py"))           # O2
+    ref.icp_fhb = _load_asis("icp_fhb", os.path.join(W12F, "icp-fhb.py"))           # O3
+    ref.icp = _load_py2("icp", os.path.join(W12M, "icp.py"))                        # O4
+    ref.slam_ekf = _load_py2("slam_ekf", os.path.join(W12M, "slam_ekf.py"))
+    return ref
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+def path_bytes(path):
+    """Canonical serialisation of a path: int32 little-endian x0,y0,x1,y1,..."""
+    return np.asarray(path, dtype="<i4").reshape(-1).tobytes()
+
+
+def save(out_dir, name, **arrays):
+    p = os.path.join(out_dir, name)
+    np.savez_compressed(p, **arrays)
+    print("wrote %s (%.1f KB)" % (p, os.path.getsize(p) / 1024.0))
+
+
+# ----------------------------------------------------------------------------
+# G1  bresenham
+# ----------------------------------------------------------------------------
+def gen_g1(ref, out_dir):
+    B = ref.bresenham.bresenham
+    # (a) every end in [-40,40]^2 from the origin: full paths, CSR layout
+    ends, flat, offs = [], [], [0]
+    for ex in range(-40, 41):
+        for ey in range(-40, 41):
+            p = B([0, 0], [ex, ey]).path
+            ends.append((ex, ey))
+            flat.extend(p)
+            offs.append(len(flat))
+    flat = np.asarray(flat, dtype=np.int8).reshape(-1, 2)
+    # (b) 2000 seeded random lines, arbitrary starts, |d| <= 2000: lengths + crc + sha
+    rng = np.random.default_rng(101)
+    starts = rng.integers(-500, 2500, size=(2000, 2))
+    delta = rng.integers(-2000, 2001, size=(2000, 2))
+    delta[:40] = [(0, 0), (1, 0), (0, -1), (7, 7), (-7, 7), (10, 3), (12, 1), (3, 10), (-1, 12), (2000, 1)] * 4
+    delta[10:20] *= -1
+    rends = starts + delta
+    lens = np.zeros(2000, dtype=np.int32)
+    crcs = np.zeros(2000, dtype=np.uint32)
+    heads = np.zeros((2000, 2, 2), dtype=np.int32)   # first and last cell
+    sha = hashlib.sha256()
+    for k in range(2000):
+        p = B([int(starts[k, 0]), int(starts[k, 1])], [int(rends[k, 0]), int(rends[k, 1])]).path
+        lens[k] = len(p)
+        b = path_bytes(p) if p else b""
+        crcs[k] = zlib.crc32(b)
+        sha.update(b)
+        if p:
+            heads[k, 0], heads[k, 1] = p[0], p[-1]
+    save(out_dir, "g1_bresenham.npz", fan_ends=np.asarray(ends, dtype=np.int8), fan_cells=flat,
+         fan_offsets=np.asarray(offs, dtype=np.int32), rand_starts=starts.astype(np.int32),
+         rand_ends=rends.astype(np.int32), rand_len=lens, rand_crc=crcs, rand_first_last=heads,
+         rand_sha256=np.frombuffer(sha.digest(), dtype=np.uint8))
+
+
+# ----------------------------------------------------------------------------
+# G2  Mapping.update
+# ----------------------------------------------------------------------------
+def gen_g2(ref, out_dir):
+    M = ref.mapping.Mapping
+    arrays = {}
+    # (a) the demo of mapping.py:53-72 with a fixed seed, for three beam counts
+    for n in (120, 200, 360):
+        rng = np.random.default_rng(n)
+        m = M(200, 200, 0.1)
+        oxs, oys, cs, pm = [], [], [], []
+        for i in range(10):
+            cx = cy = 3 - i * 0.3
+            ang = np.linspace(0, 2 * np.pi, n)
+            dist = rng.random(n) * 1 + 5
+            ox, oy = np.sin(ang) * dist, np.cos(ang) * dist
+            p = m.update(ox, oy, cx, cy)
+            oxs.append(ox), oys.append(oy), cs.append((cx, cy)), pm.append(p.astype(np.int8).copy())
+        arrays.update({"demo%d_ox" % n: np.array(oxs), "demo%d_oy" % n: np.array(oys),
+                       "demo%d_c" % n: np.array(cs), "demo%d_pmap_steps" % n: np.array(pm),
+                       "demo%d_datamap" % n: m.datamap.copy()})
+    # (b) static centre: centre-cell saturation (0.01*N per scan crosses 10 after a few scans)
+    rng = np.random.default_rng(7)
+    m = M(200, 200, 0.1)
+    n = 360
+    oxs, oys, pm = [], [], []
+    for i in range(5):
+        ang = np.linspace(-np.pi, np.pi, n)
+        dist = rng.random(n) * 3 + 2
+        ox, oy = 0.4 + np.cos(ang) * dist, -0.7 + np.sin(ang) * dist
+        p = m.update(ox, oy, np.array([0.4]), np.array([-0.7]))   # 1-element arrays, as slam_ekf.py:90 passes
+        oxs.append(ox), oys.append(oy), pm.append(p.astype(np.int8).copy())
+    arrays.update(static_ox=np.array(oxs), static_oy=np.array(oys), static_c=np.array([0.4, -0.7]),
+                  static_pmap_steps=np.array(pm), static_datamap=m.datamap.copy())
+    # (c) edge cases in one update: out-of-bounds endpoints, start == end, x < -10
+    #     truncation toward zero, inf in ox (beam skipped, :30)
+    m = M(200, 200, 0.1)
+    ox = np.array([12.5, -10.05, -10.95, 0.31, np.inf, 3.0, -14.0, 9.99, 0.0, 25.0, -9.999, 0.35])
+    oy = np.array([0.0, -10.05, 4.0, 0.32, 1.0, 30.0, -14.0, 9.99, -12.0, 25.0, 9.999, 0.31])
+    p = m.update(ox, oy, 0.3, 0.3)
+    arrays.update(edge_ox=ox, edge_oy=oy, edge_c=np.array([0.3, 0.3]), edge_pmap=p.astype(np.int8).copy(),
+                  edge_datamap=m.datamap.copy())
+    # (d) robot outside the map looking in
+    m = M(200, 200, 0.1)
+    ang = np.linspace(2.0, 4.2, 90)
+    ox, oy = 11.0 + 6 * np.cos(ang), 0.5 + 6 * np.sin(ang)
+    p = m.update(ox, oy, 11.0, 0.5)
+    arrays.update(outside_ox=ox, outside_oy=oy, outside_c=np.array([11.0, 0.5]),
+                  outside_pmap=p.astype(np.int8).copy(), outside_datamap=m.datamap.copy())
+    # (e) non-square map object (bounds come from xw, yw; the index rule stays 10/10)
+    m = M(120, 260, 0.1)
+    rng = np.random.default_rng(9)
+    ang = np.linspace(-np.pi, np.pi, 150)
+    dist = rng.random(150) * 6 + 1
+    ox, oy = -3.0 + np.cos(ang) * dist, 2.0 + np.sin(ang) * dist
+    p = m.update(ox, oy, -3.0, 2.0)
+    arrays.update(rect_ox=ox, rect_oy=oy, rect_c=np.array([-3.0, 2.0]), rect_pmap=p.astype(np.int8).copy(),
+                  rect_datamap=m.datamap.copy())
+    save(out_dir, "g2_mapping.npz", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G3  ICP
+# ----------------------------------------------------------------------------
+class _Counting:
+    """Mixin that counts findNearest calls = ICP iterations (icp.py:67)."""
+
+    def findNearest(self, src, tar):
+        self.nn_calls += 1
+        self.last_dist, self.last_idx = super().findNearest(src, tar)
+        return self.last_dist, self.last_idx
+
+
+def gen_g3(ref, out_dir):
+    ICP = type("ICPc", (_Counting, ref.icp.ICP), {})
+    with quiet():
+        icp = ICP()
+    fhb = ref.icp_fhb.ICP()
+    lt = ref.slam_ekf.SLAM_EKF.laserToNumpy
+    arrays = {}
+    # (a) findNearest on scan pairs
+    k = 0
+    for n in (120, 360):
+        for shape in ("room", "corridor", "circle"):
+            pair = syn.scan_pair(n, seed=20 + k, shape=shape)
+            tar = lt(None, pair.message(0))
+            src = lt(None, pair.message(1))
+            icp.nn_calls = 0
+            d, i = icp.findNearest(src[:2].T, tar[:2].T)
+            arrays["nn%d_ranges" % k] = pair.ranges
+            arrays["nn%d_tar" % k], arrays["nn%d_src" % k] = tar, src
+            arrays["nn%d_dist" % k], arrays["nn%d_idx" % k] = d, i.astype(np.int32)
+            k += 1
+    arrays["nn_count"] = np.array(k)
+    # (b) getTransform on 100 seeded paired sets, half of them built to hit det(R) < 0
+    rng = np.random.default_rng(33)
+    src_l, tar_l, T_l, refl = [], [], [], []
+    for c in range(100):
+        n = int(rng.integers(3, 60))
+        a = rng.normal(0, 2, size=(n, 2)) + rng.normal(0, 5, size=(1, 2))
+        th = rng.uniform(-np.pi, np.pi)
+        r = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        b = a.dot(r.T) + rng.normal(0, 3, size=(1, 2)) + rng.normal(0, 0.05, size=(n, 2))
+        if c % 2:
+            b[:, 1] = -b[:, 1] * rng.uniform(0.2, 1.0)      # mirrored: U.Vt is a reflection
+        pad = np.full((60, 2), np.nan)
+        pa, pb = pad.copy(), pad.copy()
+        pa[:n], pb[:n] = a, b
+        w = (b - b.mean(0)).T.dot(a - a.mean(0))
+        u, _, vt = np.linalg.svd(w)
+        refl.append(np.linalg.det(u.dot(vt)) < 0)
+        with quiet():
+            T_l.append(icp.getTransform(a, b))
+        src_l.append(pa), tar_l.append(pb)
+    arrays.update(gt_src=np.array(src_l), gt_tar=np.array(tar_l), gt_T=np.array(T_l),
+                  gt_reflect=np.array(refl))
+    print("getTransform reflection cases: %d / 100" % int(np.sum(refl)))
+    # (c) process: T, iteration count, last mean error; (30, 1e-3) [code default] and (10, 0) [W7 launch]
+    cases = []
+    for n in (120, 360):
+        for shape, delta, seeds in (("room", (0.05, 0.02, np.deg2rad(1.0)), (0, 1, 2)),
+                                    ("room", (0.15, -0.05, np.deg2rad(-4.0)), (3, 4)),
+                                    ("corridor", (0.10, 0.01, np.deg2rad(0.5)), (5,)),
+                                    ("circle", (0.03, 0.04, np.deg2rad(2.0)), (6,))):
+            for s in seeds:
+                cases.append((n, shape, delta, s))
+    rngs, Ts, its, errs, cfgs, ns = [], [], [], [], [], []
+    t0 = time.time()
+    for (n, shape, delta, s) in cases:
+        pair = syn.scan_pair(n, seed=s, delta=delta, shape=shape)
+        tar, src = lt(None, pair.message(0)), lt(None, pair.message(1))
+        for (mi, tol) in ((30, 0.001), (10, 0.0)):
+            if n == 360 and (mi, tol) == (10, 0.0) and s not in (0, 3):
+                continue
+            sys.modules["rospy"].get_param = lambda name, default=None, _t=tol: _t if name == "/icp/tolerance" else PARAMS.get(name, default)
+            icp.max_iter, icp.nn_calls = mi, 0
+            T = icp.process(tar, src)
+            if (mi, tol) == (30, 0.001):   # O3 cross-check (module constants 30 / 0.001)
+                T3 = fhb.process(tar, src)
+                assert np.array_equal(T, T3), "O3 and O4 disagree"
+            pad = np.full((2, 360), np.nan, dtype=np.float32)
+            pad[:, :n] = pair.ranges
+            rngs.append(pad), Ts.append(T), its.append(icp.nn_calls), ns.append(n)
+            errs.append(np.sum(icp.last_dist) / icp.last_dist.size), cfgs.append((mi, tol))
+        print("  process %s n=%d seed=%d  (%.0fs)" % (shape, n, s, time.time() - t0), flush=True)
+    arrays.update(pr_ranges=np.array(rngs), pr_n=np.array(ns, dtype=np.int32), pr_T=np.array(Ts),
+                  pr_iters=np.array(its, dtype=np.int32), pr_mean_err=np.array(errs), pr_cfg=np.array(cfgs))
+    # (d) different source / target sizes and an inf-clipped beam
+    pair = syn.scan_pair(120, seed=9)
+    r0, r1 = pair.ranges[0].copy(), pair.ranges[1, ::2].copy()
+    r0[5] = np.inf
+    m0 = syn.LaserScan(ranges=tuple(float(v) for v in r0))
+    m1 = syn.LaserScan(ranges=tuple(float(v) for v in r1))
+    tar, src = lt(None, m0), lt(None, m1)
+    sys.modules["rospy"].get_param = lambda name, default=None: PARAMS.get(name, default)
+    icp.max_iter, icp.nn_calls = 30, 0
+    T = icp.process(tar, src)
+    arrays.update(rag_r0=r0, rag_r1=r1, rag_T=T, rag_iters=np.array(icp.nn_calls))
+    save(out_dir, "g3_icp.npz", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G4  pipeline
+# ----------------------------------------------------------------------------
+def gen_g4(ref, out_dir):
+    sys.modules["rospy"].get_param = lambda name, default=None: PARAMS.get(name, default)
+    S = ref.slam_ekf.SLAM_EKF
+    arrays = {}
+    for tag, n_scan, n_beams, seed, stride in (("a", 20, 120, 5, 5), ("b", 12, 360, 6, 3)):
+        rep = syn.make_replay(n_scan * stride, n_beams, seed)
+        ranges = rep.ranges[::stride].copy()      # decimated like slam_ekf.py:65-68
+        ranges[3, 7] = np.inf                     # one dropped return: clipped to 30 m (:119)
+        node = object.__new__(S)                  # glue methods only; no ROS, no EKF
+        with quiet():
+            node.icp = ref.icp.ICP()
+        node.mapping = ref.mapping.Mapping(200, 200, 0.1)
+        poses, Ts = [], []
+        for k in range(n_scan):
+            msg = syn.LaserScan(ranges=tuple(float(v) for v in ranges[k]))
+            np_msg = node.laserToNumpy(msg)                               # slam_ekf.py:73
+            if k == 0:
+                node.tar_pc = np_msg                                      # :74-78
+                continue
+            node.src_pc = np_msg                                          # calc_odometry :109-113
+            T = node.icp.process(node.tar_pc, node.src_pc)
+            node.tar_pc = np_msg
+            with quiet():
+                node.icp.publishResult(T)                                 # dead reckoning, icp.py:185-190
+            # slam_ekf.py:89 passes xEst[:3], a 3x1 array; under the NumPy of the reference's
+            # era u2T then builds an object matrix, under NumPy 2 that raises, so the pose is
+            # handed over as three floats.  update() still gets 1-element arrays (:90).
+            x = [float(v) for v in node.icp.sensor_sta]
+            obs = node.u2T(x).dot(np_msg)                                 # :89
+            pmap = node.mapping.update(obs[0], obs[1], np.array([x[0]]), np.array([x[1]]))   # :90
+            poses.append(list(node.icp.sensor_sta)), Ts.append(T)
+        arrays.update({tag + "_ranges": ranges, tag + "_poses": np.array(poses), tag + "_T": np.array(Ts),
+                       tag + "_pmap": pmap.astype(np.int8).copy(), tag + "_datamap": node.mapping.datamap.copy(),
+                       tag + "_grid_data": np.trunc(pmap.T.reshape(-1)).astype(np.int8)})   # publishMap :270-271
+        print("  pipeline %s done" % tag, flush=True)
+    save(out_dir, "g4_pipeline.npz", **arrays)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="g1,g2,g3,g4")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    ref = load_reference()
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4)):
+        if name in args.only.split(","):
+            t0 = time.time()
+            fn(ref, args.out)
+            print("%s: %.1f s" % (name, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()
