@@ -1,0 +1,326 @@
+// Occupancy-grid kernels for gfx950 (MI355X): the float-error Bresenham ray walk of the
+// reference with integer evidence counters, the threshold/finalize pass, and the
+// stand-alone line rasteriser.
+//
+// Functional spec = the reference's Python (W12m = "W12_LiDAR SLAM/w12-mapping/
+// course_agv_slam/scripts" under /root/reference):
+//   Mapping.update   W12m/mapping.py:22-51    -> cast_ray / k_grid_update*
+//   bresenham        W12m/bresenham.py:2-58   -> ray_setup + the walk loops, k_bresenham
+//   pmap threshold   W12m/mapping.py:47-50    -> k_grid_finalize
+//   publishMap       W12m/slam_ekf.py:270-271 -> k_grid_transpose
+//
+// Evidence model (DESIGN.md "K4"): the reference adds 0.01 per pass-through cell and 20
+// on the last cell of each ray into a float64 map and thresholds at > 10.  Those sums
+// commute only as integers, so the device keeps uint32 pass / hit counters per cell
+// (atomicAdd, order-free, bit-reproducible) and the finalize kernel applies the rule the
+// float sums obey: untouched -> 50; hit >= 1 (20 > 10) or pass >= 1001 (the 1001st
+// sequential +0.01 is the first float64 sum above 10) -> 100; else 0.
+//
+// The ray walk keeps the reference's float64 error accumulation verbatim
+// (error += dy/float(dx); if error >= 0.5: y += ystep; error -= 1.0): 15 % of lines
+// differ from integer Bresenham, so anything else breaks cell parity.
+#include <hip/hip_runtime.h>
+
+#include "slam_internal.h"
+
+namespace slam {
+
+struct Ray {
+    int x0, y0, dx, ystep;   // walk origin (after steep / endpoint swaps), run length, y direction
+    double derr;
+    bool steep, flag;        // flag: the walk runs end -> start, i.e. path order is reversed (:57-58)
+};
+
+// bresenham.__init__ up to the loop (bresenham.py:10-43).  Returns false for identical
+// endpoints (empty path, :10-11).
+__device__ __forceinline__ bool ray_setup(int sx, int sy, int ex, int ey, Ray &r)
+{
+    if (sx == ex && sy == ey) return false;
+    int adx = abs(ex - sx), ady = abs(ey - sy);
+    r.steep = ady > adx;                                             // :14
+    if (r.steep) { int t = sx; sx = sy; sy = t; t = ex; ex = ey; ey = t; }   // :15-17
+    r.flag = sx > ex;                                                // :19
+    if (r.flag) { int t = sx; sx = ex; ex = t; t = sy; sy = ey; ey = t; }    // :20-29
+    r.x0 = sx; r.y0 = sy;
+    r.dx = ex - sx;                                                  // :32
+    int dy = abs(ey - sy);                                           // :33
+    r.derr = (double)dy / (double)r.dx;                              // :35  (IEEE division)
+    r.ystep = sy < ey ? 1 : -1;                                      // :40-43
+    return true;
+}
+
+// World coordinate -> cell index, int(scale * (v + off)) truncated toward zero
+// (mapping.py:33-36).  Flags what Python would raise on (NaN: ValueError, inf: OverflowError).
+__device__ __forceinline__ int to_cell(double v, double scale, double off, int &bad)
+{
+    double c = scale * (v + off);
+    if (c != c) { bad |= kStatusNaN; return 0; }
+    if (!(fabs(c) < (double)kMaxRayCells)) { bad |= kStatusOverflow; return 0; }
+    return (int)c;
+}
+
+// One ray of Mapping.update (mapping.py:38-50): +1 pass on every in-bounds cell of the
+// path except the last, +1 hit on the last.  Returns the number of in-bounds cells.
+// The first cell of the path (the ray origin, shared by every ray of the scan) is not
+// written here when `skip_first` is set: the caller adds it once per wave.
+__device__ __forceinline__ unsigned cast_ray(uint32_t *__restrict__ pass, uint32_t *__restrict__ hit, int xw, int yw,
+                                             int pcx, int pcy, int pox, int poy, bool &first_pending)
+{
+    Ray r;
+    first_pending = false;
+    if (!ray_setup(pcx, pcy, pox, poy, r)) return 0u;
+    unsigned nvis = 0;
+    double error = 0.0;                                              // :34
+    int y = r.y0;
+    for (int k = 0; k <= r.dx; ++k) {                                // :45
+        int x = r.x0 + k;
+        int lx = r.steep ? y : x, ly = r.steep ? x : y;              // :46-49
+        bool last = r.flag ? (k == 0) : (k == r.dx);                 // last cell in PATH order
+        bool first = r.flag ? (k == r.dx) : (k == 0);
+        if ((unsigned)lx < (unsigned)xw && (unsigned)ly < (unsigned)yw) {   // mapping.py:41
+            ++nvis;
+            if (first && lx == pcx && ly == pcy) {
+                first_pending = true;                                // aggregated by the caller
+            } else {
+                size_t c = (size_t)lx * yw + ly;
+                atomicAdd(last ? &hit[c] : &pass[c], 1u);            // :42-45
+            }
+        }
+        error += r.derr;                                             // :51
+        if (error >= 0.5) { y += r.ystep; error -= 1.0; }            // :53-55
+    }
+    return nvis;
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Shared tail of the two update kernels: per-wave aggregation of the origin cell and of
+// the visit counter, and the sticky status word.
+__device__ __forceinline__ void finish_wave(const GridDev &g, uint32_t *pass, int pcx, int pcy, bool first_pending,
+                                            unsigned nvis, int bad)
+{
+    unsigned long long m = __ballot(first_pending);
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicAdd(&pass[(size_t)pcx * g.yw + pcy], (unsigned)__popcll(m));
+        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
+        if (anybad) atomicOr(g.status, anybad);
+    }
+}
+
+// Mapping.update for B scans given world-frame endpoints: one workgroup per scan, one
+// lane per beam (a workgroup never spans two scans, so the origin cell is wave-uniform).
+__global__ void __launch_bounds__(256) k_grid_update(GridDev g, const double *__restrict__ ox, const double *__restrict__ oy,
+                                                     const double *__restrict__ cx, const double *__restrict__ cy, int n,
+                                                     const int32_t *__restrict__ gob)
+{
+    const int b = blockIdx.x;
+    const int gi = gob ? gob[b] : 0;
+    uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
+    int cbad = 0;                                                    // the origin is the same for every beam;
+    const int pcx = to_cell(cx[b], g.scale, g.off_x, cbad);          // :35  a bad origin only raises if some
+    const int pcy = to_cell(cy[b], g.scale, g.off_y, cbad);          // :36  beam is actually cast
+    for (int base = 0; base < n; base += blockDim.x) {
+        int i = base + threadIdx.x;
+        int bad = 0;
+        bool first_pending = false;
+        unsigned nvis = 0;
+        if (i < n) {
+            double x = ox[(size_t)b * n + i], y = oy[(size_t)b * n + i];
+            if (!(fabs(x) == INFINITY)) {                            // mapping.py:30: only ox is tested
+                int pox = to_cell(x, g.scale, g.off_x, bad);        // :33
+                int poy = to_cell(y, g.scale, g.off_y, bad);        // :34
+                bad |= cbad;
+                if (!bad) nvis = cast_ray(pass, hit, g.xw, g.yw, pcx, pcy, pox, poy, first_pending);
+            }
+        }
+        finish_wave(g, pass, pcx, pcy, first_pending, nvis, bad);
+    }
+}
+
+// Replay form: the world-frame endpoints are formed here from the raw ranges and the
+// dead-reckoned pose (slam_ekf.py:89 with u2T of :130-137 and laserToNumpy of :115-123),
+// all in float64 whatever storage type the ICP point buffers use, so cells never depend
+// on that choice.  Block (k-1, l) handles scan k of trajectory l.
+__global__ void __launch_bounds__(256) k_grid_update_replay(GridDev g, const float *__restrict__ ranges,
+                                                            const double *__restrict__ cos_t, const double *__restrict__ sin_t,
+                                                            const double *__restrict__ poses, int n_scan, int n,
+                                                            const int32_t *__restrict__ got)
+{
+    const int km1 = blockIdx.x, l = blockIdx.y;
+    const int gi = got ? got[l] : 0;
+    uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
+    const double *pose = poses + 3 * ((size_t)l * (n_scan - 1) + km1);
+    const double px = pose[0], py = pose[1];
+    const double c = cos(pose[2]), s = sin(pose[2]);
+    const float *r = ranges + ((size_t)l * n_scan + km1 + 1) * n;
+    int cbad = 0;
+    const int pcx = to_cell(px, g.scale, g.off_x, cbad);
+    const int pcy = to_cell(py, g.scale, g.off_y, cbad);
+    for (int base = 0; base < n; base += blockDim.x) {
+        int i = base + threadIdx.x;
+        int bad = 0;
+        bool first_pending = false;
+        unsigned nvis = 0;
+        if (i < n) {
+            double rr = (double)r[i];
+            if (rr == INFINITY) rr = 30.0;                           // slam_ekf.py:119
+            double lx = cos_t[i] * rr, ly = sin_t[i] * rr;           // :122
+            double x = c * lx + (-s) * ly + px * 1.0;                // u2T(pose).dot(pc), :89
+            double y = s * lx + c * ly + py * 1.0;
+            if (!(fabs(x) == INFINITY)) {
+                int pox = to_cell(x, g.scale, g.off_x, bad);
+                int poy = to_cell(y, g.scale, g.off_y, bad);
+                bad |= cbad;
+                if (!bad) nvis = cast_ray(pass, hit, g.xw, g.yw, pcx, pcy, pox, poy, first_pending);
+            }
+        }
+        finish_wave(g, pass, pcx, pcy, first_pending, nvis, bad);
+    }
+}
+
+static inline int ray_block(int n)
+{
+    int blk = ((n + kWave - 1) / kWave) * kWave;
+    return blk > 256 ? 256 : (blk < kWave ? kWave : blk);
+}
+
+hipError_t launch_grid_update(const GridDev &g, const double *ox, const double *oy, const double *cx, const double *cy,
+                              int B, int n, const int32_t *gob, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_update, dim3(B), dim3(ray_block(n)), 0, s, g, ox, oy, cx, cy, n, gob);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                     const double *poses, int L, int n_scan, int n, const int32_t *got, hipStream_t s)
+{
+    if (n_scan < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_grid_update_replay, dim3(n_scan - 1, L), dim3(ray_block(n)), 0, s, g, ranges, cos_t, sin_t,
+                       poses, n_scan, n, got);
+    return hipGetLastError();
+}
+
+// mapping.py:47-50 applied to the integer counters (see the header comment).
+__global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,
+                                                       size_t cells, uint32_t pass_thresh, int hit_occupies,
+                                                       int8_t *__restrict__ pmap)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; c < cells; c += stride) {
+        if (c + 4 <= cells) {
+            uint4 p = *reinterpret_cast<const uint4 *>(pass + c);
+            uint4 h = *reinterpret_cast<const uint4 *>(hit + c);
+            const uint32_t pp[4] = {p.x, p.y, p.z, p.w}, hh[4] = {h.x, h.y, h.z, h.w};
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool touched = (pp[k] | hh[k]) != 0;
+                bool occ = (hit_occupies && hh[k] >= 1) || pp[k] >= pass_thresh;
+                uint32_t v = touched ? (occ ? 100u : 0u) : 50u;
+                out |= v << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(pmap + c) = out;
+        } else {
+            for (size_t e = c; e < cells; ++e) {
+                bool touched = (pass[e] | hit[e]) != 0;
+                bool occ = (hit_occupies && hit[e] >= 1) || pass[e] >= pass_thresh;
+                pmap[e] = touched ? (occ ? 100 : 0) : 50;
+            }
+        }
+    }
+}
+
+hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s)
+{
+    size_t per = (size_t)g.xw * g.yw, cells = per * gcount;
+    size_t blocks = (cells / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells,
+                       g.pass_thresh, g.hit_occupies, pmap);
+    return hipGetLastError();
+}
+
+// datamap view of the counters: free_inc*pass + hit_inc*hit (mapping.py:43,45).
+__global__ void __launch_bounds__(256) k_grid_datamap(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,
+                                                      size_t cells, double free_inc, double hit_inc, double *__restrict__ out)
+{
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x)
+        out[c] = free_inc * (double)pass[c] + hit_inc * (double)hit[c];
+}
+
+hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s)
+{
+    size_t per = (size_t)g.xw * g.yw;
+    size_t blocks = (per + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_grid_datamap, dim3(blocks), dim3(256), 0, s, g.pass + per * gi, g.hit + per * gi, per, g.free_inc,
+                       g.hit_inc, datamap);
+    return hipGetLastError();
+}
+
+// publishMap layout (slam_ekf.py:270-271): data[y*xw + x] = pmap[x][y]; 32x32 LDS tile
+// transpose so both sides are coalesced.
+__global__ void __launch_bounds__(256) k_grid_transpose(const int8_t *__restrict__ pmap, int xw, int yw, int8_t *__restrict__ data)
+{
+    __shared__ int8_t tile[32][33];
+    int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int x = x0 + r, y = y0 + tx;
+        if (x < xw && y < yw) tile[r][tx] = pmap[(size_t)x * yw + y];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int y = y0 + r, x = x0 + tx;
+        if (x < xw && y < yw) data[(size_t)y * xw + x] = tile[tx][r];
+    }
+}
+
+hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_transpose, dim3((xw + 31) / 32, (yw + 31) / 32), dim3(256), 0, s, pmap, xw, yw, data);
+    return hipGetLastError();
+}
+
+// bresenham(start, end).path (bresenham.py:2-58): one lane per line.
+__global__ void __launch_bounds__(256) k_bresenham(const int32_t *__restrict__ starts, const int32_t *__restrict__ ends, int B,
+                                                   const int64_t *__restrict__ offsets, int32_t *__restrict__ lens,
+                                                   int32_t *__restrict__ cells)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    Ray r;
+    if (!ray_setup(starts[2 * b], starts[2 * b + 1], ends[2 * b], ends[2 * b + 1], r)) { lens[b] = 0; return; }
+    lens[b] = r.dx + 1;
+    if (!cells) return;
+    int32_t *out = cells + 2 * offsets[b];
+    double error = 0.0;
+    int y = r.y0;
+    for (int k = 0; k <= r.dx; ++k) {
+        int x = r.x0 + k;
+        int j = r.flag ? r.dx - k : k;                               // path.reverse(), :57-58
+        out[2 * (size_t)j] = r.steep ? y : x;
+        out[2 * (size_t)j + 1] = r.steep ? x : y;
+        error += r.derr;
+        if (error >= 0.5) { y += r.ystep; error -= 1.0; }
+    }
+}
+
+hipError_t launch_bresenham(const int32_t *starts, const int32_t *ends, int B, const int64_t *offsets, int32_t *lens,
+                            int32_t *cells, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bresenham, dim3((B + 255) / 256), dim3(256), 0, s, starts, ends, B, offsets, lens, cells);
+    return hipGetLastError();
+}
+
+}  // namespace slam

@@ -1,0 +1,457 @@
+// ICP scan-matching kernels for gfx950 (MI355X): brute-force nearest neighbour,
+// closed-form 2-D Kabsch, the whole ICP.process loop in one launch, polar->Cartesian
+// conversion and dead-reckoning pose composition.
+//
+// Functional spec = the reference's Python (paths relative to /root/reference,
+// W12m = "W12_LiDAR SLAM/w12-mapping/course_agv_slam/scripts"):
+//   ICP.process      W12m/icp.py:38-88      -> k_icp
+//   ICP.findNearest  W12m/icp.py:90-114     -> nn_search / k_nn
+//   ICP.getTransform W12m/icp.py:149-179    -> kabsch_from_sums / k_kabsch
+//   laserToNumpy     W12m/slam_ekf.py:115-123 -> k_scan_to_points
+//   publishResult    W12m/icp.py:185-190    -> k_pose_compose
+//
+// Design (DESIGN.md "K2"): one workgroup per scan pair, one lane per query point.  The
+// target cloud is staged once in LDS as float64 (x,y) pairs and every lane sweeps it with
+// broadcast ds_read_b128; the source point, its original copy and the running best live
+// in registers for the whole solve, so HBM sees each point once.  All arithmetic is
+// float64 (the reference is float64 and a float32 distance would flip near-tied
+// neighbours, moving the pose by ~1e-4); gfx950 issues f64 FMA at half
+// the f32 rate, which still leaves the path >100x above its throughput target.
+// The library is compiled with -ffp-contract=off: fused multiply-adds appear only where
+// written as fma().
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "slam_internal.h"
+
+namespace slam {
+
+__device__ __forceinline__ double ld(const double *p, long i) { return p[i]; }
+__device__ __forceinline__ double ld(const float *p, long i) { return (double)p[i]; }
+__device__ __forceinline__ double ld(const __half *p, long i) { return (double)__half2float(p[i]); }
+__device__ __forceinline__ void st(double *p, long i, double v) { p[i] = v; }
+__device__ __forceinline__ void st(float *p, long i, double v) { p[i] = (float)v; }
+// float64 -> float16 with ONE rounding (as numpy.astype(float16) does): go through a
+// float32 rounded to odd, so the final round-to-nearest sees the sticky information.
+__device__ __forceinline__ void st(__half *p, long i, double v)
+{
+    float f = (float)v;
+    if ((double)f != v && v == v) {
+        unsigned u = __float_as_uint(f);
+        if (fabs((double)f) > fabs(v)) u -= 1u;   // back to the truncated magnitude
+        f = __uint_as_float(u | 1u);
+    }
+    p[i] = __float2half_rn(f);
+}
+
+// Sum NV doubles over the workgroup; every thread receives the (bitwise identical)
+// totals.  Fixed butterfly + fixed wave order: deterministic run to run.  `scratch` must
+// alternate between two buffers on consecutive calls (no trailing barrier).
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int nwaves, int wave, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        v[k] = x;
+    }
+    if (nwaves == 1) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) scratch[k * kMaxWaves + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += scratch[k * kMaxWaves + w];
+        v[k] = s;
+    }
+}
+
+struct Rigid2 {
+    double c, s, tx, ty;
+};
+
+// ICP.getTransform (icp.py:149-179) from reduced sums.  The reference takes the SVD of
+// the 2x2 matrix W = BB^T.AA (:160-161), R = U.Vt with the reflection fix (:162-169);
+// that R is exactly rot(atan2(W10 - W01, W00 + W11)) (checked against the
+// SVD form in tests/test_oracle_golden.py::test_get_transform), evaluated here without
+// trigonometry as (A, B)/hypot(A, B).
+__device__ __forceinline__ Rigid2 kabsch_from_sums(double cax, double cay, double cbx, double cby, double w00,
+                                                   double w01, double w10, double w11)
+{
+    double A = w00 + w11, B = w10 - w01;
+    double h = sqrt(A * A + B * B);
+    Rigid2 r;
+    r.c = h > 0.0 ? A / h : 1.0;
+    r.s = h > 0.0 ? B / h : 0.0;
+    r.tx = cbx - (r.c * cax - r.s * cay);   // t = centroid_B - R.centroid_A (:172)
+    r.ty = cby - (r.s * cax + r.c * cay);
+    return r;
+}
+
+// ICP.findNearest (icp.py:90-114) for one query against the LDS-resident target cloud.
+// Strict '<' keeps the lowest index on ties (:103); NaN never wins.  Squared distances
+// are compared (sqrt is monotone); the distance itself is sqrt of the winner.
+__device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, int n_tar, double sx, double sy,
+                                          double &best_d2, int &best_j)
+{
+    double best = INFINITY;
+    int bj = 0;
+#pragma unroll 8
+    for (int j = 0; j < n_tar; ++j) {
+        double2 t = tarL[j];
+        double dx = sx - t.x, dy = sy - t.y;
+        double d2 = fma(dy, dy, dx * dx);
+        bool c = d2 < best;
+        best = c ? d2 : best;
+        bj = c ? j : bj;
+    }
+    best_d2 = best;
+    best_j = bj;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL)
+{
+    for (int j = threadIdx.x; j < n_tar; j += blockDim.x) tarL[j] = make_double2(ld(tar, j), ld(tar, (long)n_tar + j));
+}
+
+// ---------------------------------------------------------------------------------
+// k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
+// ---------------------------------------------------------------------------------
+template <typename T, int QPT>
+__global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *tarL = reinterpret_cast<double2 *>(smem);
+    double *red = reinterpret_cast<double *>(smem + (size_t)a.n_tar * sizeof(double2));  // [2][5][kMaxWaves]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const long be = (long)b + (a.ppt ? b / a.ppt : 0);
+    const T *tar = static_cast<const T *>(a.tar) + be * a.tar_stride;
+    const T *src = static_cast<const T *>(a.src) + be * a.src_stride;
+    const int n_src = a.n_src, n_tar = a.n_tar;
+
+    stage_target(tar, n_tar, tarL);
+
+    double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
+    bool ok[QPT];
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+        int i = tid + q * blockDim.x;
+        ok[q] = i < n_src;
+        double x = ok[q] ? ld(src, i) : 0.0, y = ok[q] ? ld(src, (long)n_src + i) : 0.0;
+        if (a.prior) {
+            const double *p = a.prior + 6 * (long)b;
+            double xp = p[0] * x + p[1] * y + p[2];
+            double yp = p[3] * x + p[4] * y + p[5];
+            x = xp; y = yp;
+        }
+        sx[q] = ax[q] = x;
+        sy[q] = ay[q] = y;
+    }
+    __syncthreads();
+
+    const double dn = (double)n_src;
+    double pre_error = 0.0, mean_error = 0.0;
+    int iters = 0, par = 0;
+    for (int it = 0; it < a.max_iter; ++it) {
+        double mx[QPT], my[QPT];
+        double v[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            double d2; int j;
+            nn_search(tarL, n_tar, sx[q], sy[q], d2, j);          // icp.py:67
+            double2 m = tarL[j];
+            mx[q] = m.x; my[q] = m.y;
+            double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
+            if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dist; }
+        }
+        block_sum<5>(v, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+        double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;   // icp.py:154-155
+        double w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            if (ok[q]) {
+                double aax = sx[q] - cax, aay = sy[q] - cay, bbx = mx[q] - cbx, bby = my[q] - cby;
+                w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;   // :160
+            }
+        }
+        block_sum<4>(w, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+        Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);    // :69
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {                              // src = T.src (:71)
+            double nx = r.c * sx[q] + (-r.s) * sy[q] + r.tx;
+            double ny = r.s * sx[q] + r.c * sy[q] + r.ty;
+            sx[q] = nx; sy[q] = ny;
+        }
+        ++iters;
+        mean_error = v[4] / dn;                                      // :75
+        if (fabs(pre_error - mean_error) < a.tol) break;             // :76-77
+        pre_error = mean_error;
+    }
+
+    // final T = getTransform(A_original, src_final) (icp.py:81)
+    double v[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < QPT; ++q)
+        if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
+    block_sum<4>(v, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+    double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
+    double w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+        if (ok[q]) {
+            double aax = ax[q] - cax, aay = ay[q] - cay, bbx = sx[q] - cbx, bby = sy[q] - cby;
+            w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
+        }
+    }
+    block_sum<4>(w, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+    if (tid == 0) {
+        Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
+        double *To = a.T_out + 9 * (long)b;
+        To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
+        To[3] = r.s; To[4] = r.c;  To[5] = r.ty;
+        To[6] = 0.0; To[7] = 0.0;  To[8] = 1.0;
+        if (a.iters_out) a.iters_out[b] = iters;
+        if (a.err_out) a.err_out[b] = mean_error;
+    }
+}
+
+static inline int icp_block(int n_src, int qpt)
+{
+    int per = (n_src + qpt - 1) / qpt;
+    int blk = ((per + kWave - 1) / kWave) * kWave;
+    return blk < kWave ? kWave : blk;
+}
+
+template <typename T>
+static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
+{
+    int qpt = (a.n_src + 1023) / 1024;
+    size_t lds = (size_t)a.n_tar * sizeof(double2) + 2 * 5 * kMaxWaves * sizeof(double);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid(a.B);
+#define SLAM_ICP_CASE(Q)                                                                                        \
+    {                                                                                                           \
+        if (lds > 64 * 1024) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            if (e != hipSuccess) return e;                                                                      \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_icp<T, Q>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                        \
+    }
+    if (qpt <= 1) SLAM_ICP_CASE(1)
+    else if (qpt <= 2) SLAM_ICP_CASE(2)
+    else if (qpt <= 4) SLAM_ICP_CASE(4)
+    else if (qpt <= 8) SLAM_ICP_CASE(8)
+    else return hipErrorInvalidValue;   // n_src > 8192
+#undef SLAM_ICP_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_icp(const IcpArgs &a, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case SLAM_F64: return launch_icp_t<double>(a, s);
+    case SLAM_F32: return launch_icp_t<float>(a, s);
+    case SLAM_F16: return launch_icp_t<__half>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------
+// k_nn: ICP.findNearest as a stand-alone operator (icp.py:90-114).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_nn(const T *src, const T *tar, int n_src, int n_tar, double *dist, int32_t *idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *tarL = reinterpret_cast<double2 *>(smem);
+    const int b = blockIdx.y;
+    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL);
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = i < n_src;
+    const T *s = src + (long)b * 2 * n_src;
+    double sx = ok ? ld(s, i) : 0.0, sy = ok ? ld(s, (long)n_src + i) : 0.0;
+    double d2; int j;
+    nn_search(tarL, n_tar, sx, sy, d2, j);
+    if (ok) {
+        dist[(long)b * n_src + i] = (d2 < INFINITY) ? sqrt(d2) : 0.0;
+        idx[(long)b * n_src + i] = j;
+    }
+}
+
+template <typename T>
+static hipError_t launch_nn_t(const void *src, const void *tar, int B, int n_src, int n_tar, double *dist,
+                              int32_t *idx, hipStream_t s)
+{
+    size_t lds = (size_t)n_tar * sizeof(double2);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nn<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((n_src + 255) / 256, B);
+    hipLaunchKernelGGL((k_nn<T>), grid, dim3(256), lds, s, static_cast<const T *>(src), static_cast<const T *>(tar),
+                       n_src, n_tar, dist, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_nn(const void *src, const void *tar, int B, int n_src, int n_tar, int dtype, double *dist,
+                     int32_t *idx, hipStream_t s)
+{
+    switch (dtype) {
+    case SLAM_F64: return launch_nn_t<double>(src, tar, B, n_src, n_tar, dist, idx, s);
+    case SLAM_F32: return launch_nn_t<float>(src, tar, B, n_src, n_tar, dist, idx, s);
+    case SLAM_F16: return launch_nn_t<__half>(src, tar, B, n_src, n_tar, dist, idx, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------
+// k_kabsch: ICP.getTransform on paired rows (icp.py:149-179), one workgroup per pair.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kabsch(const double *src, const double *tar, int n, double *T_out)
+{
+    __shared__ double red[2 * 4 * kMaxWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const double *a = src + (long)b * 2 * n, *bb = tar + (long)b * 2 * n;
+    double v[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += blockDim.x) { v[0] += a[i]; v[1] += a[n + i]; v[2] += bb[i]; v[3] += bb[n + i]; }
+    block_sum<4>(v, red, nwaves, wave, lane);
+    double dn = (double)n;
+    double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
+    double w[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += blockDim.x) {
+        double aax = a[i] - cax, aay = a[n + i] - cay, bbx = bb[i] - cbx, bby = bb[n + i] - cby;
+        w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
+    }
+    block_sum<4>(w, red + 4 * kMaxWaves, nwaves, wave, lane);
+    if (tid == 0) {
+        Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
+        double *To = T_out + 9 * (long)b;
+        To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
+        To[3] = r.s; To[4] = r.c;  To[5] = r.ty;
+        To[6] = 0.0; To[7] = 0.0;  To[8] = 1.0;
+    }
+}
+
+hipError_t launch_kabsch(const double *src, const double *tar, int B, int n, double *T_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kabsch, dim3(B), dim3(256), 0, s, src, tar, n, T_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// k_scan_to_points: laserToNumpy (W7/icp.py:182-195; W12m/slam_ekf.py:115-123).
+// x = cos(angle_i) * r, y = sin(angle_i) * r in float64, one IEEE multiply each, with the
+// caller's NumPy-computed cos/sin tables: bit-identical to the reference's products.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_scan_to_points(const float *__restrict__ ranges, const double *__restrict__ cos_t,
+                                                        const double *__restrict__ sin_t, long total, int n, int clip_inf,
+                                                        T *__restrict__ pts)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long b = e / n;
+        int i = (int)(e - b * n);
+        double r = (double)ranges[e];
+        if (clip_inf && r == INFINITY) r = 30.0;                    // MAX_LASER_RANGE, slam_ekf.py:18,119
+        st(pts, b * 2 * n + i, cos_t[i] * r);
+        st(pts, b * 2 * n + n + i, sin_t[i] * r);
+    }
+}
+
+hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const double *sin_t, long total, int n,
+                                 int clip_inf, int dtype, void *pts, hipStream_t s)
+{
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    switch (dtype) {
+    case SLAM_F64:
+        hipLaunchKernelGGL((k_scan_to_points<double>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<double *>(pts));
+        break;
+    case SLAM_F32:
+        hipLaunchKernelGGL((k_scan_to_points<float>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<float *>(pts));
+        break;
+    case SLAM_F16:
+        hipLaunchKernelGGL((k_scan_to_points<__half>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<__half *>(pts));
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// k_pose_compose: the pose update of ICP.publishResult (icp.py:185-190) chained over a
+// trajectory.  The recurrence is serial, so the transcendental work is done by all lanes
+// (delta_yaw; cos/sin of the heading BEFORE each step) and only the two running sums are
+// walked by one lane, in the reference's evaluation order:
+//   x = (x + cos(th)*tx) - sin(th)*ty;  y = (y + sin(th)*tx) + cos(th)*ty;  th = th + dyaw.
+// ---------------------------------------------------------------------------------
+constexpr int kComposeChunk = 1024;
+
+__global__ void __launch_bounds__(256) k_pose_compose(const double *__restrict__ T, const double *__restrict__ pose0, int n,
+                                                      double *__restrict__ poses)
+{
+    __shared__ double dyaw[kComposeChunk], thb[kComposeChunk];
+    __shared__ double pa[kComposeChunk], pb[kComposeChunk], pc[kComposeChunk], pd[kComposeChunk];
+    __shared__ double carry[3];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const double *Tl = T + 9 * (long)l * n;
+    double *Pl = poses + 3 * (long)l * n;
+    if (tid == 0) { carry[0] = pose0[3 * l]; carry[1] = pose0[3 * l + 1]; carry[2] = pose0[3 * l + 2]; }
+    for (int base = 0; base < n; base += kComposeChunk) {
+        int cnt = min(kComposeChunk, n - base);
+        for (int k = tid; k < cnt; k += blockDim.x) {
+            const double *t = Tl + 9 * (long)(base + k);
+            dyaw[k] = atan2(t[3], t[0]);                             // icp.py:185
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double th = carry[2];
+            for (int k = 0; k < cnt; ++k) { thb[k] = th; th = th + dyaw[k]; }   // :190
+            carry[2] = th;
+        }
+        __syncthreads();
+        for (int k = tid; k < cnt; k += blockDim.x) {
+            const double *t = Tl + 9 * (long)(base + k);
+            double c = cos(thb[k]), s = sin(thb[k]);
+            pa[k] = c * t[2]; pb[k] = s * t[5]; pc[k] = s * t[2]; pd[k] = c * t[5];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double x = carry[0], y = carry[1];
+            for (int k = 0; k < cnt; ++k) {
+                x = (x + pa[k]) - pb[k];                             // :188
+                y = (y + pc[k]) + pd[k];                             // :189
+                pa[k] = x; pc[k] = y;
+            }
+            carry[0] = x; carry[1] = y;
+        }
+        __syncthreads();
+        for (int k = tid; k < cnt; k += blockDim.x) {
+            double *p = Pl + 3 * (long)(base + k);
+            p[0] = pa[k]; p[1] = pc[k]; p[2] = thb[k] + dyaw[k];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pose_compose, dim3(L), dim3(256), 0, s, T, pose0, n, poses);
+    return hipGetLastError();
+}
+
+}  // namespace slam

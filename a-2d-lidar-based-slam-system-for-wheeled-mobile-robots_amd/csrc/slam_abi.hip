@@ -1,0 +1,740 @@
+// C-ABI layer of libslamhip.so (include/slam_hip.h): contexts, workspaces, error
+// reporting, host<->device staging and the launch sequences.  No compute happens on the
+// host; without a gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "slam_internal.h"
+
+using namespace slam;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(SLAM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                                                             \
+    do {                                                                                               \
+        if (!(cond)) return fail(SLAM_ERR_INVALID, "%s: %s", __func__, msg);                           \
+    } while (0)
+
+size_t dtype_size(int dtype)
+{
+    switch (dtype) {
+    case SLAM_F64: return 8;
+    case SLAM_F32: return 4;
+    case SLAM_F16: return 2;
+    }
+    return 0;
+}
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+struct Pending {
+    int kind;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct slam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Arena staging;   // device copies of host arguments (host-pointer entry points)
+    Arena scratch;   // temporaries of *_dev sequences
+    int *status = nullptr;
+    bool timing = false;
+    std::vector<hipEvent_t> pool;
+    std::vector<Pending> pending;
+    double ms[SLAM_K_COUNT] = {0};
+    int64_t launches[SLAM_K_COUNT] = {0};
+};
+
+struct slam_grid {
+    GridDev d;
+    unsigned long long *visits = nullptr;
+    int8_t *pmap_one = nullptr;    // [xw][yw] read-back staging
+    double *datamap_one = nullptr;
+};
+
+namespace {
+
+int arena_reserve(slam_ctx *c, Arena &a, size_t bytes)
+{
+    a.used = 0;
+    if (bytes <= a.cap) return SLAM_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (a.base) HIPCHK(hipFree(a.base));
+    a.base = nullptr;
+    a.cap = 0;
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&a.base), want);
+    if (e != hipSuccess) return fail(SLAM_ERR_NOMEM, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e));
+    a.cap = want;
+    return SLAM_OK;
+}
+
+template <typename T>
+T *carve(Arena &a, size_t count)
+{
+    size_t off = align_up(a.used);
+    a.used = off + count * sizeof(T);
+    return reinterpret_cast<T *>(a.base + off);
+}
+
+// RAII event bracket around one kernel family launch.
+struct Timed {
+    slam_ctx *c;
+    int kind;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(slam_ctx *ctx, int k) : c(ctx), kind(k)
+    {
+        if (!c->timing) return;
+        e0 = get();
+        e1 = get();
+        if (e0 && e1) (void)hipEventRecord(e0, c->stream);
+    }
+    ~Timed()
+    {
+        if (!c->timing || !e0 || !e1) return;
+        (void)hipEventRecord(e1, c->stream);
+        c->pending.push_back({kind, e0, e1});
+    }
+    hipEvent_t get()
+    {
+        if (!c->pool.empty()) {
+            hipEvent_t e = c->pool.back();
+            c->pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+int use(slam_ctx *c)
+{
+    if (!c) return fail(SLAM_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    return SLAM_OK;
+}
+
+int status_to_code(int st)
+{
+    if (st & kStatusNaN) return fail(SLAM_ERR_NAN, "cannot convert float NaN to integer (mapping.py:33-36)");
+    if (st & kStatusOverflow)
+        return fail(SLAM_ERR_OVERFLOW, "cannot convert float infinity to integer / cell index beyond 2^20 (mapping.py:33-36)");
+    return SLAM_OK;
+}
+
+int check_status_sync(slam_ctx *c)
+{
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, c->status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (st) {
+        HIPCHK(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return status_to_code(st);
+}
+
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream))
+#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream))
+#define TRY(expr)                                                                                      \
+    do {                                                                                               \
+        int rc_ = (expr);                                                                              \
+        if (rc_ != SLAM_OK) return rc_;                                                                \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int slam_abi_version(void) { return SLAM_ABI_VERSION; }
+
+const char *slam_last_error(void) { return g_err.c_str(); }
+
+int slam_create(int device, void *stream, slam_ctx **out)
+{
+    if (!out) return fail(SLAM_ERR_INVALID, "slam_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(SLAM_ERR_NODEVICE, "no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(SLAM_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SLAM_ERR_NODEVICE, "device %d is %s; libslamhip is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    slam_ctx *c = new slam_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(SLAM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    e = hipMalloc(reinterpret_cast<void **>(&c->status), 256);
+    if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 256, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SLAM_ERR_HIP, "context init: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SLAM_OK;
+}
+
+int slam_destroy(slam_ctx *c)
+{
+    if (!c) return SLAM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->staging.base) (void)hipFree(c->staging.base);
+    if (c->scratch.base) (void)hipFree(c->scratch.base);
+    if (c->status) (void)hipFree(c->status);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SLAM_OK;
+}
+
+int slam_synchronize(slam_ctx *c)
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_check_status(slam_ctx *c)
+{
+    TRY(use(c));
+    return check_status_sync(c);
+}
+
+int slam_timing_enable(slam_ctx *c, int on)
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) { c->pool.push_back(p.e0); c->pool.push_back(p.e1); }
+    c->pending.clear();
+    for (int k = 0; k < SLAM_K_COUNT; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
+    c->timing = on != 0;
+    return SLAM_OK;
+}
+
+int slam_timing_read(slam_ctx *c, double ms_out[SLAM_K_COUNT], int64_t launches_out[SLAM_K_COUNT])
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            c->ms[p.kind] += ms;
+            c->launches[p.kind] += 1;
+        }
+        c->pool.push_back(p.e0);
+        c->pool.push_back(p.e1);
+    }
+    c->pending.clear();
+    for (int k = 0; k < SLAM_K_COUNT; ++k) {
+        if (ms_out) ms_out[k] = c->ms[k];
+        if (launches_out) launches_out[k] = c->launches[k];
+        c->ms[k] = 0;
+        c->launches[k] = 0;
+    }
+    return SLAM_OK;
+}
+
+/* ---- ICP ------------------------------------------------------------------------ */
+
+int slam_scan_to_points_dev(slam_ctx *c, const float *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                            int clip_inf, int dtype, void *pts_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pts_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "B and n must be positive");
+    REQUIRE(dtype_size(dtype), "unknown dtype");
+    Timed t(c, SLAM_K_POINTS);
+    HIPCHK(launch_scan_to_points(ranges, cos_t, sin_t, (long)B * n, n, clip_inf, dtype, pts_out, c->stream));
+    return SLAM_OK;
+}
+
+int slam_scan_to_points(slam_ctx *c, const float *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                        int clip_inf, int dtype, void *pts_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pts_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "B and n must be positive");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    size_t nr = (size_t)B * n;
+    TRY(arena_reserve(c, c->staging, align_up(nr * 4) + 2 * align_up((size_t)n * 8) + align_up(2 * nr * ds) + 1024));
+    float *d_r = carve<float>(c->staging, nr);
+    double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
+    char *d_p = carve<char>(c->staging, 2 * nr * ds);
+    H2D(d_r, ranges, nr * 4);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_s, sin_t, (size_t)n * 8);
+    TRY(slam_scan_to_points_dev(c, d_r, d_c, d_s, B, n, clip_inf, dtype, d_p));
+    D2H(pts_out, d_p, 2 * nr * ds);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_nn_dev(slam_ctx *c, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype, double *dist,
+                int32_t *idx)
+{
+    TRY(use(c));
+    REQUIRE(src && tar && dist && idx, "null pointer");
+    REQUIRE(B > 0 && n_src > 0 && n_tar > 0, "sizes must be positive");
+    REQUIRE(dtype_size(dtype), "unknown dtype");
+    REQUIRE((size_t)n_tar * 16 <= 160 * 1024, "n_tar too large for the LDS-resident target (max 10240 points)");
+    Timed t(c, SLAM_K_NN);
+    HIPCHK(launch_nn(src, tar, B, n_src, n_tar, dtype, dist, idx, c->stream));
+    return SLAM_OK;
+}
+
+int slam_nn(slam_ctx *c, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype, double *dist,
+            int32_t *idx)
+{
+    TRY(use(c));
+    REQUIRE(src && tar && dist && idx, "null pointer");
+    REQUIRE(B > 0 && n_src > 0 && n_tar > 0, "sizes must be positive");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    size_t bs = (size_t)B * 2 * n_src * ds, bt = (size_t)B * 2 * n_tar * ds, q = (size_t)B * n_src;
+    TRY(arena_reserve(c, c->staging, align_up(bs) + align_up(bt) + align_up(q * 8) + align_up(q * 4) + 1024));
+    char *d_s = carve<char>(c->staging, bs), *d_t = carve<char>(c->staging, bt);
+    double *d_d = carve<double>(c->staging, q);
+    int32_t *d_i = carve<int32_t>(c->staging, q);
+    H2D(d_s, src, bs);
+    H2D(d_t, tar, bt);
+    TRY(slam_nn_dev(c, d_s, d_t, B, n_src, n_tar, dtype, d_d, d_i));
+    D2H(dist, d_d, q * 8);
+    D2H(idx, d_i, q * 4);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_kabsch2d_dev(slam_ctx *c, const double *src, const double *tar, int B, int n, double *T_out)
+{
+    TRY(use(c));
+    REQUIRE(src && tar && T_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "sizes must be positive");
+    Timed t(c, SLAM_K_KABSCH);
+    HIPCHK(launch_kabsch(src, tar, B, n, T_out, c->stream));
+    return SLAM_OK;
+}
+
+int slam_kabsch2d(slam_ctx *c, const double *src, const double *tar, int B, int n, double *T_out)
+{
+    TRY(use(c));
+    REQUIRE(src && tar && T_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "sizes must be positive");
+    size_t bp = (size_t)B * 2 * n * 8;
+    TRY(arena_reserve(c, c->staging, 2 * align_up(bp) + align_up((size_t)B * 72) + 1024));
+    double *d_s = carve<double>(c->staging, (size_t)B * 2 * n), *d_t = carve<double>(c->staging, (size_t)B * 2 * n);
+    double *d_T = carve<double>(c->staging, (size_t)B * 9);
+    H2D(d_s, src, bp);
+    H2D(d_t, tar, bp);
+    TRY(slam_kabsch2d_dev(c, d_s, d_t, B, n, d_T));
+    D2H(T_out, d_T, (size_t)B * 72);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int n_tar, int n_src, int dtype,
+                       int tar_shared, int src_shared, const double *prior, int max_iter, double tol, double *T_out,
+                       int32_t *iters_out, double *mean_err_out)
+{
+    TRY(use(c));
+    REQUIRE(tar && src && T_out, "null pointer");
+    REQUIRE(B > 0 && n_src > 0 && n_tar > 0, "sizes must be positive");
+    REQUIRE(max_iter >= 0, "max_iter must be >= 0");
+    REQUIRE(dtype_size(dtype), "unknown dtype");
+    REQUIRE(n_src <= 8192, "n_src > 8192 not supported");
+    REQUIRE((size_t)n_tar * 16 + 2048 <= 160 * 1024, "n_tar too large for the LDS-resident target (max ~10000 points)");
+    IcpArgs a;
+    a.tar = tar; a.src = src; a.prior = prior;
+    a.tar_stride = tar_shared ? 0 : 2L * n_tar;
+    a.src_stride = src_shared ? 0 : 2L * n_src;
+    a.ppt = 0;
+    a.B = B; a.n_tar = n_tar; a.n_src = n_src; a.max_iter = max_iter; a.tol = tol;
+    a.T_out = T_out; a.iters_out = iters_out; a.err_out = mean_err_out;
+    Timed t(c, SLAM_K_ICP);
+    HIPCHK(launch_icp(a, dtype, c->stream));
+    return SLAM_OK;
+}
+
+int slam_icp_batch(slam_ctx *c, const void *tar, const void *src, int B, int n_tar, int n_src, int dtype, int tar_shared,
+                   int src_shared, const double *prior, int max_iter, double tol, double *T_out, int32_t *iters_out,
+                   double *mean_err_out)
+{
+    TRY(use(c));
+    REQUIRE(tar && src && T_out, "null pointer");
+    REQUIRE(B > 0 && n_src > 0 && n_tar > 0, "sizes must be positive");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    size_t bt = (size_t)(tar_shared ? 1 : B) * 2 * n_tar * ds, bs = (size_t)(src_shared ? 1 : B) * 2 * n_src * ds;
+    TRY(arena_reserve(c, c->staging, align_up(bt) + align_up(bs) + align_up((size_t)B * 48) + align_up((size_t)B * 72) +
+                                         align_up((size_t)B * 4) + align_up((size_t)B * 8) + 2048));
+    char *d_t = carve<char>(c->staging, bt), *d_s = carve<char>(c->staging, bs);
+    double *d_p = prior ? carve<double>(c->staging, (size_t)B * 6) : nullptr;
+    double *d_T = carve<double>(c->staging, (size_t)B * 9);
+    int32_t *d_i = carve<int32_t>(c->staging, B);
+    double *d_e = carve<double>(c->staging, B);
+    H2D(d_t, tar, bt);
+    H2D(d_s, src, bs);
+    if (prior) H2D(d_p, prior, (size_t)B * 48);
+    TRY(slam_icp_batch_dev(c, d_t, d_s, B, n_tar, n_src, dtype, tar_shared, src_shared, d_p, max_iter, tol, d_T, d_i, d_e));
+    D2H(T_out, d_T, (size_t)B * 72);
+    if (iters_out) D2H(iters_out, d_i, (size_t)B * 4);
+    if (mean_err_out) D2H(mean_err_out, d_e, (size_t)B * 8);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_pose_compose_dev(slam_ctx *c, const double *T, const double *pose0, int L, int n, double *poses_out)
+{
+    TRY(use(c));
+    REQUIRE(T && pose0 && poses_out, "null pointer");
+    REQUIRE(L > 0 && n > 0, "sizes must be positive");
+    Timed t(c, SLAM_K_COMPOSE);
+    HIPCHK(launch_pose_compose(T, pose0, L, n, poses_out, c->stream));
+    return SLAM_OK;
+}
+
+int slam_pose_compose(slam_ctx *c, const double *T, const double *pose0, int L, int n, double *poses_out)
+{
+    TRY(use(c));
+    REQUIRE(T && pose0 && poses_out, "null pointer");
+    REQUIRE(L > 0 && n > 0, "sizes must be positive");
+    size_t nt = (size_t)L * n;
+    TRY(arena_reserve(c, c->staging, align_up(nt * 72) + align_up((size_t)L * 24) + align_up(nt * 24) + 1024));
+    double *d_T = carve<double>(c->staging, nt * 9), *d_0 = carve<double>(c->staging, (size_t)L * 3);
+    double *d_P = carve<double>(c->staging, nt * 3);
+    H2D(d_T, T, nt * 72);
+    H2D(d_0, pose0, (size_t)L * 24);
+    TRY(slam_pose_compose_dev(c, d_T, d_0, L, n, d_P));
+    D2H(poses_out, d_P, nt * 24);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+/* ---- occupancy grid --------------------------------------------------------------- */
+
+int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double off_x, double off_y, double free_inc,
+                     double hit_inc, double thresh, slam_grid **out)
+{
+    TRY(use(c));
+    REQUIRE(out, "out is null");
+    *out = nullptr;
+    REQUIRE(G > 0 && xw > 0 && yw > 0, "G, xw, yw must be positive");
+    REQUIRE(scale > 0 && std::isfinite(scale) && std::isfinite(off_x) && std::isfinite(off_y), "bad index rule");
+    REQUIRE(free_inc > 0 && hit_inc > 0 && std::isfinite(thresh), "increments must be positive");
+    REQUIRE(hit_inc > thresh,
+            "hit_inc <= thresh makes the occupied test depend on the order of float additions (the +4 variant of "
+            "w12-mapping-online); not supported");
+    slam_grid *g = new slam_grid();
+    size_t cells = (size_t)G * xw * yw;
+    g->d.G = G; g->d.xw = xw; g->d.yw = yw;
+    g->d.scale = scale; g->d.off_x = off_x; g->d.off_y = off_y;
+    g->d.free_inc = free_inc; g->d.hit_inc = hit_inc;
+    g->d.hit_occupies = hit_inc > thresh;
+    // Smallest k whose float64 running sum of k additions of free_inc exceeds thresh
+    // (mapping.py:43,47): 1001 for (0.01, 10).  Evaluated with the same sequential IEEE adds.
+    {
+        volatile double acc = 0.0;
+        uint32_t k = 0;
+        while (!(acc > thresh) && k < 0xfffffff0u) { acc = acc + free_inc; ++k; }
+        g->d.pass_thresh = k;
+    }
+    g->d.status = c->status;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d.pass), cells * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->d.hit), cells * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->visits), 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->pmap_one), align_up((size_t)xw * yw));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->datamap_one), (size_t)xw * yw * 8);
+    if (e != hipSuccess) {
+        slam_grid_destroy(c, g);
+        return fail(SLAM_ERR_NOMEM, "grid allocation (%zu cells): %s", cells, hipGetErrorString(e));
+    }
+    g->d.visits = g->visits;
+    *out = g;
+    return slam_grid_reset(c, g);
+}
+
+int slam_grid_destroy(slam_ctx *c, slam_grid *g)
+{
+    if (!g) return SLAM_OK;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (g->d.pass) (void)hipFree(g->d.pass);
+    if (g->d.hit) (void)hipFree(g->d.hit);
+    if (g->visits) (void)hipFree(g->visits);
+    if (g->pmap_one) (void)hipFree(g->pmap_one);
+    if (g->datamap_one) (void)hipFree(g->datamap_one);
+    delete g;
+    return SLAM_OK;
+}
+
+int slam_grid_reset(slam_ctx *c, slam_grid *g)
+{
+    TRY(use(c));
+    REQUIRE(g, "null grid");
+    size_t cells = (size_t)g->d.G * g->d.xw * g->d.yw;
+    HIPCHK(hipMemsetAsync(g->d.pass, 0, cells * 4, c->stream));
+    HIPCHK(hipMemsetAsync(g->d.hit, 0, cells * 4, c->stream));
+    HIPCHK(hipMemsetAsync(g->visits, 0, 256, c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const double *oy, const double *cx, const double *cy,
+                         int B, int n, const int32_t *grid_of_batch)
+{
+    TRY(use(c));
+    REQUIRE(g && ox && oy && cx && cy, "null pointer");
+    REQUIRE(B > 0 && n > 0, "sizes must be positive");
+    Timed t(c, SLAM_K_GRID);
+    HIPCHK(launch_grid_update(g->d, ox, oy, cx, cy, B, n, grid_of_batch, c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_update(slam_ctx *c, slam_grid *g, const double *ox, const double *oy, const double *cx, const double *cy,
+                     int B, int n, const int32_t *grid_of_batch)
+{
+    TRY(use(c));
+    REQUIRE(g && ox && oy && cx && cy, "null pointer");
+    REQUIRE(B > 0 && n > 0, "sizes must be positive");
+    if (grid_of_batch)
+        for (int b = 0; b < B; ++b) REQUIRE(grid_of_batch[b] >= 0 && grid_of_batch[b] < g->d.G, "grid_of_batch out of range");
+    size_t np = (size_t)B * n;
+    TRY(arena_reserve(c, c->staging, 2 * align_up(np * 8) + 2 * align_up((size_t)B * 8) + align_up((size_t)B * 4) + 2048));
+    double *d_x = carve<double>(c->staging, np), *d_y = carve<double>(c->staging, np);
+    double *d_cx = carve<double>(c->staging, B), *d_cy = carve<double>(c->staging, B);
+    int32_t *d_g = grid_of_batch ? carve<int32_t>(c->staging, B) : nullptr;
+    H2D(d_x, ox, np * 8);
+    H2D(d_y, oy, np * 8);
+    H2D(d_cx, cx, (size_t)B * 8);
+    H2D(d_cy, cy, (size_t)B * 8);
+    if (grid_of_batch) H2D(d_g, grid_of_batch, (size_t)B * 4);
+    TRY(slam_grid_update_dev(c, g, d_x, d_y, d_cx, d_cy, B, n, d_g));
+    return check_status_sync(c);
+}
+
+int slam_grid_finalize_dev(slam_ctx *c, slam_grid *g, int8_t *pmap_dev)
+{
+    TRY(use(c));
+    REQUIRE(g && pmap_dev, "null pointer");
+    Timed t(c, SLAM_K_FINALIZE);
+    HIPCHK(launch_grid_finalize(g->d, 0, g->d.G, pmap_dev, c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_read(slam_ctx *c, slam_grid *g, int gi, int8_t *pmap, double *datamap, uint32_t *pass, uint32_t *hit)
+{
+    TRY(use(c));
+    REQUIRE(g, "null grid");
+    REQUIRE(gi >= 0 && gi < g->d.G, "grid index out of range");
+    size_t per = (size_t)g->d.xw * g->d.yw;
+    if (pmap) {
+        {
+            Timed t(c, SLAM_K_FINALIZE);
+            HIPCHK(launch_grid_finalize(g->d, gi, 1, g->pmap_one, c->stream));
+        }
+        D2H(pmap, g->pmap_one, per);
+    }
+    if (datamap) {
+        HIPCHK(launch_grid_datamap(g->d, gi, g->datamap_one, c->stream));
+        D2H(datamap, g->datamap_one, per * 8);
+    }
+    if (pass) D2H(pass, g->d.pass + per * gi, per * 4);
+    if (hit) D2H(hit, g->d.hit + per * gi, per * 4);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_occupancy_data(slam_ctx *c, slam_grid *g, int gi, int8_t *data)
+{
+    TRY(use(c));
+    REQUIRE(g && data, "null pointer");
+    REQUIRE(gi >= 0 && gi < g->d.G, "grid index out of range");
+    size_t per = (size_t)g->d.xw * g->d.yw;
+    TRY(arena_reserve(c, c->scratch, align_up(per) + 1024));
+    int8_t *d_data = carve<int8_t>(c->scratch, per);
+    HIPCHK(launch_grid_finalize(g->d, gi, 1, g->pmap_one, c->stream));
+    HIPCHK(launch_grid_transpose(g->pmap_one, g->d.xw, g->d.yw, d_data, c->stream));
+    D2H(data, d_data, per);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_visits(slam_ctx *c, slam_grid *g, uint64_t *visits_out)
+{
+    TRY(use(c));
+    REQUIRE(g && visits_out, "null pointer");
+    unsigned long long v = 0;
+    D2H(&v, g->visits, sizeof v);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *visits_out = v;
+    return SLAM_OK;
+}
+
+int slam_bresenham_batch(slam_ctx *c, const int32_t *starts, const int32_t *ends, int B, const int64_t *offsets,
+                         int32_t *lens_out, int32_t *cells_out, int64_t total_cells)
+{
+    TRY(use(c));
+    REQUIRE(starts && ends && lens_out, "null pointer");
+    REQUIRE(B > 0, "B must be positive");
+    REQUIRE(!cells_out || (offsets && total_cells >= 0), "cells_out needs offsets and total_cells");
+    for (int b = 0; b < B; ++b) {
+        int64_t dx = (int64_t)ends[2 * b] - starts[2 * b], dy = (int64_t)ends[2 * b + 1] - starts[2 * b + 1];
+        int64_t len = std::max(std::llabs(dx), std::llabs(dy)) + 1;
+        if (len > 2 * (int64_t)kMaxRayCells) return fail(SLAM_ERR_OVERFLOW, "line %d longer than 2^21 cells", b);
+        if (cells_out && (offsets[b] < 0 || offsets[b] + len > total_cells))
+            return fail(SLAM_ERR_INVALID, "line %d does not fit cells_out", b);
+    }
+    size_t tc = cells_out ? (size_t)total_cells : 0;
+    TRY(arena_reserve(c, c->staging, 2 * align_up((size_t)B * 8) + align_up((size_t)B * 8) + align_up((size_t)B * 4) +
+                                         align_up(tc * 8) + 2048));
+    int32_t *d_s = carve<int32_t>(c->staging, (size_t)B * 2), *d_e = carve<int32_t>(c->staging, (size_t)B * 2);
+    int64_t *d_o = carve<int64_t>(c->staging, B);
+    int32_t *d_l = carve<int32_t>(c->staging, B);
+    int32_t *d_c = cells_out ? carve<int32_t>(c->staging, tc * 2) : nullptr;
+    H2D(d_s, starts, (size_t)B * 8);
+    H2D(d_e, ends, (size_t)B * 8);
+    if (cells_out) H2D(d_o, offsets, (size_t)B * 8);
+    {
+        Timed t(c, SLAM_K_BRESENHAM);
+        HIPCHK(launch_bresenham(d_s, d_e, B, d_o, d_l, d_c, c->stream));
+    }
+    D2H(lens_out, d_l, (size_t)B * 4);
+    if (cells_out && tc) D2H(cells_out, d_c, tc * 8);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+/* ---- fused replay ------------------------------------------------------------------ */
+
+int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const double *sin_t, int L, int n_scan, int n,
+                    int dtype, int max_iter, double tol, const double *pose0, slam_grid *grid, const int32_t *grid_of_traj,
+                    void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pose0 && pts_ws && poses_out, "null pointer");
+    REQUIRE(L > 0 && n_scan >= 2 && n > 0, "need L > 0, n_scan >= 2, n > 0");
+    REQUIRE(max_iter >= 0, "max_iter must be >= 0");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    REQUIRE(n <= 8192 && (size_t)n * 16 + 2048 <= 160 * 1024, "n too large");
+    const long pairs = (long)L * (n_scan - 1);
+    REQUIRE(pairs < (1L << 31), "too many scan pairs for one launch");
+    double *T = T_out;
+    if (!T) {
+        TRY(arena_reserve(c, c->scratch, align_up((size_t)pairs * 72) + 1024));
+        T = carve<double>(c->scratch, (size_t)pairs * 9);
+    }
+    {
+        Timed t(c, SLAM_K_POINTS);
+        HIPCHK(launch_scan_to_points(ranges, cos_t, sin_t, (long)L * n_scan * n, n, 1, dtype, pts_ws, c->stream));
+    }
+    {
+        IcpArgs a;
+        a.tar = pts_ws;
+        a.src = static_cast<const char *>(pts_ws) + 2 * (size_t)n * ds;   // scan k is the source, k-1 the target
+        a.prior = nullptr;
+        a.tar_stride = a.src_stride = 2L * n;
+        a.ppt = n_scan - 1;
+        a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
+        a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
+        Timed t(c, SLAM_K_ICP);
+        HIPCHK(launch_icp(a, dtype, c->stream));
+    }
+    {
+        Timed t(c, SLAM_K_COMPOSE);
+        HIPCHK(launch_pose_compose(T, pose0, L, n_scan - 1, poses_out, c->stream));
+    }
+    if (grid) {
+        Timed t(c, SLAM_K_GRID);
+        HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
+    }
+    return SLAM_OK;
+}
+
+int slam_replay(slam_ctx *c, const float *ranges, const double *cos_t, const double *sin_t, int L, int n_scan, int n,
+                int dtype, int max_iter, double tol, const double *pose0, slam_grid *grid, const int32_t *grid_of_traj,
+                double *poses_out, double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pose0 && poses_out, "null pointer");
+    REQUIRE(L > 0 && n_scan >= 2 && n > 0, "need L > 0, n_scan >= 2, n > 0");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    if (grid && grid_of_traj)
+        for (int l = 0; l < L; ++l) REQUIRE(grid_of_traj[l] >= 0 && grid_of_traj[l] < grid->d.G, "grid_of_traj out of range");
+    size_t nr = (size_t)L * n_scan * n, pairs = (size_t)L * (n_scan - 1);
+    TRY(arena_reserve(c, c->staging, align_up(nr * 4) + 2 * align_up((size_t)n * 8) + align_up((size_t)L * 24) +
+                                         align_up(2 * nr * ds) + align_up(pairs * 72) + align_up(pairs * 24) +
+                                         align_up(pairs * 4) + align_up((size_t)L * 4) + 4096));
+    float *d_r = carve<float>(c->staging, nr);
+    double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
+    double *d_0 = carve<double>(c->staging, (size_t)L * 3);
+    char *d_pts = carve<char>(c->staging, 2 * nr * ds);
+    double *d_T = carve<double>(c->staging, pairs * 9), *d_P = carve<double>(c->staging, pairs * 3);
+    int32_t *d_it = carve<int32_t>(c->staging, pairs);
+    int32_t *d_g = (grid && grid_of_traj) ? carve<int32_t>(c->staging, L) : nullptr;
+    H2D(d_r, ranges, nr * 4);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_s, sin_t, (size_t)n * 8);
+    H2D(d_0, pose0, (size_t)L * 24);
+    if (d_g) H2D(d_g, grid_of_traj, (size_t)L * 4);
+    TRY(slam_replay_dev(c, d_r, d_c, d_s, L, n_scan, n, dtype, max_iter, tol, d_0, grid, d_g, d_pts, d_P, d_T, d_it));
+    D2H(poses_out, d_P, pairs * 24);
+    if (T_out) D2H(T_out, d_T, pairs * 72);
+    if (iters_out) D2H(iters_out, d_it, pairs * 4);
+    return check_status_sync(c);
+}
+
+}  // extern "C"

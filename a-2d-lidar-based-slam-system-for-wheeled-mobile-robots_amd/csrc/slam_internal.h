@@ -1,0 +1,64 @@
+// Internal declarations shared by the kernel files and the C-ABI layer of libslamhip.so.
+// gfx950 (MI355X) only; wavefront = 64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slam_hip.h"
+
+namespace slam {
+
+constexpr int kWave = 64;
+constexpr int kMaxWaves = 16;            // 1024-thread workgroups
+constexpr int kMaxRayCells = 1 << 20;    // longest ray the grid kernels will walk (cells)
+
+enum : int { kStatusNaN = 1, kStatusOverflow = 2 };
+
+// ---- ICP ---------------------------------------------------------------------------
+struct IcpArgs {
+    const void *tar, *src;     // point buffers, [2][n] per set, storage type = template T
+    const double *prior;       // nullable [B][6]
+    long tar_stride, src_stride;  // elements between consecutive sets (0: shared)
+    int ppt;                   // replay addressing: pairs per trajectory (0: plain batch)
+    int B, n_tar, n_src, max_iter;
+    double tol;
+    double *T_out;             // [B][9]
+    int32_t *iters_out;        // nullable [B]
+    double *err_out;           // nullable [B]
+};
+
+hipError_t launch_icp(const IcpArgs &a, int dtype, hipStream_t s);
+hipError_t launch_nn(const void *src, const void *tar, int B, int n_src, int n_tar, int dtype, double *dist,
+                     int32_t *idx, hipStream_t s);
+hipError_t launch_kabsch(const double *src, const double *tar, int B, int n, double *T_out, hipStream_t s);
+hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const double *sin_t, long total,
+                                 int n, int clip_inf, int dtype, void *pts, hipStream_t s);
+hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s);
+
+// ---- grid --------------------------------------------------------------------------
+struct GridDev {
+    int G, xw, yw;
+    double scale, off_x, off_y;
+    uint32_t *pass, *hit;          // [G][xw][yw]
+    unsigned long long *visits;    // in-bounds cell visits since reset
+    int *status;                   // sticky kStatus* bits (context-wide)
+    uint32_t pass_thresh;          // smallest pass count whose float64 running sum exceeds thresh
+    int hit_occupies;              // hit_inc > thresh: one hit marks the cell occupied
+    double free_inc, hit_inc;
+};
+
+hipError_t launch_grid_update(const GridDev &g, const double *ox, const double *oy, const double *cx,
+                              const double *cy, int B, int n, const int32_t *grid_of_batch, hipStream_t s);
+// world points are formed in-kernel from ranges and poses (slam_ekf.py:89): scan k>=1 of
+// trajectory l uses poses[l][k-1].
+hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, const double *cos_t,
+                                     const double *sin_t, const double *poses, int L, int n_scan, int n,
+                                     const int32_t *grid_of_traj, hipStream_t s);
+hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
+hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
+hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);
+hipError_t launch_bresenham(const int32_t *starts, const int32_t *ends, int B, const int64_t *offsets,
+                            int32_t *lens, int32_t *cells, hipStream_t s);
+
+}  // namespace slam

@@ -156,11 +156,14 @@ class Replay:
 
 
 def make_replay(n_scans: int, n_beams: int = 360, seed: int = 1, room_scale: float = 1.0,
-                noise: float = RANGE_SIGMA) -> Replay:
+                noise: float = RANGE_SIGMA, stride: int = 1) -> Replay:
     """SURVEY.md 8(d) cfg2/cfg4/cfg5 style replay (seed 1: cfg2; 10-17: cfg4; 3 with
-    ``room_scale=2, n_beams=1080``: cfg5)."""
+    ``room_scale=2, n_beams=1080``: cfg5).  ``stride`` keeps every stride-th message of the
+    10 Hz stream, as the reference's callbacks do before processing a scan (every 5th in
+    W12m/slam_ekf.py:65-68, every 6th in W7/icp.py:51-54): ``n_scans`` is the number of
+    PROCESSED scans, spaced ``stride * 0.1`` s apart."""
     world = World.room(room_scale)
-    poses = trajectory(world, n_scans, seed)
+    poses = trajectory(world, n_scans * stride, seed)[::stride]
     ranges = scans_from_poses(world, poses, n_beams, seed, noise)
     return Replay(ranges=ranges, poses_true=poses, seed=seed, room_scale=room_scale)
 

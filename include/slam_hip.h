@@ -1,0 +1,183 @@
+/*
+ * slam_hip.h - C ABI of libslamhip.so: the MI355X (gfx950) implementation of the
+ * per-scan SLAM hot path of zjwzcx/A-2D-LiDAR-based-SLAM-System-for-Wheeled-Mobile-Robots.
+ *
+ * The reference has no FFI layer (it is pure Python 2 / NumPy); its boundary for this
+ * path is the Python class API of course_agv_slam/scripts.  Each entry
+ * point below names the reference interface it replaces.  Reference paths:
+ *   W12m = "W12_LiDAR SLAM/w12-mapping/course_agv_slam/scripts"
+ *   W7   = "W7_Dead Reckoning (ICP)/course_agv_slam/scripts"
+ * The ctypes binding a maintainer of the reference would add is shown in INTEGRATION.md
+ * and implemented in the package's _abi.py.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (SLAM_OK) or a negative SLAM_ERR_*;
+ *    slam_last_error() returns the message of the calling thread's last failure.
+ *  - a slam_ctx owns one HIP stream (or borrows the caller's) and a device workspace;
+ *    use one context per host thread.  Nothing here falls back to the CPU: without a
+ *    usable gfx950 device slam_create fails.
+ *  - functions without suffix take HOST pointers, copy in, run the kernels, copy out and
+ *    synchronise; *_dev functions take DEVICE pointers (e.g. torch.Tensor.data_ptr()),
+ *    only enqueue work on the context's stream and do not synchronise.
+ *  - point sets are structure-of-arrays: one set is 2*n values, the n x coordinates
+ *    then the n y coordinates ("[2][n]").  The reference's third row of ones
+ *    (icp.py:42-49) is not stored.  `dtype` is the STORAGE type of a point buffer
+ *    (SLAM_F64 / SLAM_F32 / SLAM_F16); all arithmetic is float64 regardless.
+ *  - T is a 3x3 row-major float64 matrix [[R, t], [0, 0, 1]] exactly as ICP.process
+ *    returns it; poses are (x, y, theta) float64.
+ *  - grids are [xw][yw] row-major (x outer) as mapping.py:14-15.
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_ABI_VERSION 1
+
+typedef struct slam_ctx slam_ctx;
+typedef struct slam_grid slam_grid;
+
+enum {
+    SLAM_OK = 0,
+    SLAM_ERR_INVALID = -1,  /* bad argument (null pointer, non-positive size, unknown dtype) */
+    SLAM_ERR_HIP = -2,      /* a HIP runtime call or kernel launch failed                    */
+    SLAM_ERR_NOMEM = -3,    /* device or host allocation failed                              */
+    SLAM_ERR_NAN = -4,      /* NaN world coordinate: the reference raises ValueError from
+                               int(nan) at mapping.py:33                                     */
+    SLAM_ERR_OVERFLOW = -5, /* infinite / unrepresentable cell index: the reference raises
+                               OverflowError from int(inf) at mapping.py:33-36 (or would walk
+                               a ray of more than 2^20 cells)                                */
+    SLAM_ERR_NODEVICE = -6  /* no gfx950 device visible                                      */
+};
+
+enum { SLAM_F64 = 0, SLAM_F32 = 1, SLAM_F16 = 2 };
+
+/* kernel families timed by slam_timing_* */
+enum { SLAM_K_POINTS = 0, SLAM_K_ICP = 1, SLAM_K_COMPOSE = 2, SLAM_K_GRID = 3, SLAM_K_FINALIZE = 4,
+       SLAM_K_NN = 5, SLAM_K_KABSCH = 6, SLAM_K_BRESENHAM = 7, SLAM_K_COUNT = 8 };
+
+int slam_abi_version(void);
+const char *slam_last_error(void);
+
+/* ---- context ------------------------------------------------------------------ */
+/* device: HIP ordinal.  stream: a hipStream_t to enqueue on (e.g. torch's current
+ * stream), or NULL to create a private one. */
+int slam_create(int device, void *stream, slam_ctx **out);
+int slam_destroy(slam_ctx *ctx);
+int slam_synchronize(slam_ctx *ctx);
+/* Synchronise and return-and-clear the sticky data error raised by kernels since the
+ * last call (SLAM_OK, SLAM_ERR_NAN or SLAM_ERR_OVERFLOW). */
+int slam_check_status(slam_ctx *ctx);
+/* Per-kernel-family timing with HIP events on the context's stream (bench.py roofline).
+ * read: synchronises, adds up elapsed ms and launch counts since the last reset. */
+int slam_timing_enable(slam_ctx *ctx, int on);
+int slam_timing_read(slam_ctx *ctx, double ms_out[SLAM_K_COUNT], int64_t launches_out[SLAM_K_COUNT]);
+
+/* ---- ICP ------------------------------------------------------------------------ */
+/* Replaces ICP.laserToNumpy (W7/icp.py:182-195) and SLAM_EKF.laserToNumpy
+ * (W12m/slam_ekf.py:115-123; clip_inf != 0 applies its inf -> 30 m rule, :119).
+ * ranges [B][n] float32; cos_t, sin_t [n] = cos/sin(numpy.linspace(angle_min, angle_max, n))
+ * computed by the caller; pts_out [B][2][n] of `dtype`. */
+int slam_scan_to_points(slam_ctx *ctx, const float *ranges, const double *cos_t, const double *sin_t,
+                        int B, int n, int clip_inf, int dtype, void *pts_out);
+int slam_scan_to_points_dev(slam_ctx *ctx, const float *ranges, const double *cos_t, const double *sin_t,
+                            int B, int n, int clip_inf, int dtype, void *pts_out);
+
+/* Replaces ICP.findNearest(src, tar) (W12m/icp.py:90-114): brute-force nearest
+ * neighbour, lowest index on ties, (distance 0, index 0) when nothing compares less
+ * than inf.  src [B][2][n_src], tar [B][2][n_tar]; dist [B][n_src], idx [B][n_src]. */
+int slam_nn(slam_ctx *ctx, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype,
+            double *dist, int32_t *idx);
+int slam_nn_dev(slam_ctx *ctx, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype,
+                double *dist, int32_t *idx);
+
+/* Replaces ICP.getTransform(src, tar) (W12m/icp.py:149-179): rigid 2-D fit of paired
+ * rows; src, tar [B][2][n] float64; T_out [B][9]. */
+int slam_kabsch2d(slam_ctx *ctx, const double *src, const double *tar, int B, int n, double *T_out);
+int slam_kabsch2d_dev(slam_ctx *ctx, const double *src, const double *tar, int B, int n, double *T_out);
+
+/* Replaces ICP.process(tar_pc, src_pc) (W12m/icp.py:38-88) and the loop body of
+ * ICP.laserCallback (W7/icp.py:74-92) for B independent pairs in one launch.
+ * tar [B][2][n_tar] (or one shared set when tar_shared != 0), src likewise.
+ * prior: NULL, or [B][6] row-major 2x3 matrices applied to the source points first
+ * (x' = p0*x + p1*y + p2; y' = p3*x + p4*y + p5): the perturbed-prior particle batch of
+ * BASELINE.json configs[2]; the returned T maps the perturbed source.
+ * T_out [B][9]; iters_out [B] and mean_err_out [B] may be NULL. */
+int slam_icp_batch(slam_ctx *ctx, const void *tar, const void *src, int B, int n_tar, int n_src,
+                   int dtype, int tar_shared, int src_shared, const double *prior, int max_iter,
+                   double tol, double *T_out, int32_t *iters_out, double *mean_err_out);
+int slam_icp_batch_dev(slam_ctx *ctx, const void *tar, const void *src, int B, int n_tar, int n_src,
+                       int dtype, int tar_shared, int src_shared, const double *prior, int max_iter,
+                       double tol, double *T_out, int32_t *iters_out, double *mean_err_out);
+
+/* Replaces the pose part of ICP.publishResult(T) (W7/icp.py:153-158 = W12m/icp.py:185-190)
+ * applied along L trajectories of n steps: T [L][n][9], pose0 [L][3] -> poses_out [L][n][3]
+ * (pose after each step; theta is not wrapped). */
+int slam_pose_compose(slam_ctx *ctx, const double *T, const double *pose0, int L, int n, double *poses_out);
+int slam_pose_compose_dev(slam_ctx *ctx, const double *T, const double *pose0, int L, int n, double *poses_out);
+
+/* ---- occupancy grid --------------------------------------------------------------- */
+/* Replaces Mapping.__init__(xw, yw, xyreso) (W12m/mapping.py:8-20) for G independent
+ * maps.  Cell index rule: int(scale * (x + off)) truncated toward zero; the reference
+ * hard-codes scale = off_x = off_y = 10 (:33-36).  free_inc / hit_inc / thresh are the
+ * +0.01 / +20 / >10 of :43-47.  Evidence is held as integer pass / hit counters. */
+int slam_grid_create(slam_ctx *ctx, int G, int xw, int yw, double scale, double off_x, double off_y,
+                     double free_inc, double hit_inc, double thresh, slam_grid **out);
+int slam_grid_destroy(slam_ctx *ctx, slam_grid *grid);
+int slam_grid_reset(slam_ctx *ctx, slam_grid *grid);
+
+/* Replaces Mapping.update(ox, oy, center_x, center_y) (W12m/mapping.py:22-51) for B
+ * scans: ox, oy [B][n] world-frame beam endpoints, cx, cy [B] ray origins;
+ * grid_of_batch [B] selects the map each scan is cast into (NULL: all into map 0). */
+int slam_grid_update(slam_ctx *ctx, slam_grid *grid, const double *ox, const double *oy, const double *cx,
+                     const double *cy, int B, int n, const int32_t *grid_of_batch);
+int slam_grid_update_dev(slam_ctx *ctx, slam_grid *grid, const double *ox, const double *oy,
+                         const double *cx, const double *cy, int B, int n, const int32_t *grid_of_batch);
+
+/* Read map g back (what Mapping.update returns, mapping.py:51, plus the state behind it).
+ * Any output may be NULL.  pmap [xw][yw] int8 in {0, 50, 100}; datamap [xw][yw] float64
+ * = free_inc*pass + hit_inc*hit; pass, hit [xw][yw] uint32. */
+int slam_grid_read(slam_ctx *ctx, slam_grid *grid, int g, int8_t *pmap, double *datamap, uint32_t *pass,
+                   uint32_t *hit);
+/* Device-side finalize of all G maps into pmap_dev [G][xw][yw] int8 (no synchronise). */
+int slam_grid_finalize_dev(slam_ctx *ctx, slam_grid *grid, int8_t *pmap_dev);
+/* Replaces the data layout of SLAM_EKF.publishMap (W12m/slam_ekf.py:270-271):
+ * data[y*xw + x] = int8(pmap[x][y]). */
+int slam_grid_occupancy_data(slam_ctx *ctx, slam_grid *grid, int g, int8_t *data);
+/* Number of in-bounds cell visits accumulated since creation / reset (SURVEY.md 8d "C"). */
+int slam_grid_visits(slam_ctx *ctx, slam_grid *grid, uint64_t *visits_out);
+
+/* Replaces bresenham(start, end).path (W12m/bresenham.py:2-58), B lines at once.
+ * starts, ends [B][2] int32.  lens_out [B] receives each path length; cells_out (may be
+ * NULL) receives the paths, line b at cells_out + 2*offsets[b] (x, y interleaved), with
+ * room for max(|dx|,|dy|)+1 cells each. */
+int slam_bresenham_batch(slam_ctx *ctx, const int32_t *starts, const int32_t *ends, int B,
+                         const int64_t *offsets, int32_t *lens_out, int32_t *cells_out, int64_t total_cells);
+
+/* ---- fused replay ------------------------------------------------------------------ */
+/* The per-scan unit of BASELINE.json (one ICP.process + one Mapping.update) over L scan
+ * streams of n_scan scans: SLAM_EKF.laserCallback (W12m/slam_ekf.py:63-95) without its
+ * out-of-scope EKF / landmark steps, the map being cast from the dead-reckoned ICP pose.
+ * ranges [L][n_scan][n] float32; pose0 [L][3]; grid may be NULL (ICP + poses only);
+ * grid_of_traj [L] or NULL (all into map 0).
+ * poses_out [L][n_scan-1][3]; T_out [L][n_scan-1][9], iters_out [L][n_scan-1] may be NULL.
+ * dtype: storage type of the intermediate point buffers the ICP reads. */
+int slam_replay(slam_ctx *ctx, const float *ranges, const double *cos_t, const double *sin_t, int L,
+                int n_scan, int n, int dtype, int max_iter, double tol, const double *pose0,
+                slam_grid *grid, const int32_t *grid_of_traj, double *poses_out, double *T_out,
+                int32_t *iters_out);
+/* Device form: additionally needs a caller-provided point buffer pts_ws of
+ * L*n_scan*2*n elements of `dtype`. */
+int slam_replay_dev(slam_ctx *ctx, const float *ranges, const double *cos_t, const double *sin_t, int L,
+                    int n_scan, int n, int dtype, int max_iter, double tol, const double *pose0,
+                    slam_grid *grid, const int32_t *grid_of_traj, void *pts_ws, double *poses_out,
+                    double *T_out, int32_t *iters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

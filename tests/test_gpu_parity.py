@@ -1,0 +1,432 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libslamhip.so), against
+(1) the golden vectors produced by the reference's own code and (2) the CPU oracle on the
+same seeded inputs.  Run on the MI355X box with ``-m gpu``.
+
+Bars (BASELINE.json north_star): cell indices / counters / iteration counts / NN indices
+bit-exact; float64 poses and transforms within 1e-9 (target bar: 1e-5 m / 1e-5 rad)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import c_oracle as co
+from oracle import oracle_np as on
+
+pytestmark = pytest.mark.gpu
+FTOL = 1e-9
+AMIN, AMAX = -3.14159, 3.14159
+
+
+@pytest.fixture(scope="module")
+def slam():
+    p = pkg()
+    p._abi.default_context()   # fails loudly when there is no gfx950 device
+    return p
+
+
+class Msg:
+    def __init__(self, ranges, angle_min=AMIN, angle_max=AMAX):
+        self.ranges = tuple(float(v) for v in ranges)
+        self.angle_min, self.angle_max = angle_min, angle_max
+
+
+# ------------------------------------------------------------------ bresenham (G1)
+def test_bresenham_fan_golden(slam, g1):
+    ends = g1["fan_ends"].astype(np.int32)
+    paths = slam.rasterize(np.zeros_like(ends), ends)
+    cells, offs = g1["fan_cells"], g1["fan_offsets"]
+    for k, p in enumerate(paths):
+        assert np.array_equal(p, cells[offs[k]:offs[k + 1]].astype(np.int32)), ends[k]
+
+
+def test_bresenham_random_golden(slam, g1):
+    paths = slam.rasterize(g1["rand_starts"], g1["rand_ends"])
+    for k, p in enumerate(paths):
+        assert len(p) == g1["rand_len"][k]
+        assert zlib.crc32(p.astype("<i4").tobytes()) == g1["rand_crc"][k], k
+
+
+def test_bresenham_class_surface(slam):
+    b = slam.bresenham([3, 4], [3, 4])
+    assert b.path == [] and b.flag == 0
+    b = slam.bresenham([0, 0], [-7, 3])
+    assert b.path == on.bresenham_path([0, 0], [-7, 3]) and b.flag == 1 and b.path[0] == (0, 0) and b.path[-1] == (-7, 3)
+    b = slam.bresenham((2, 9), (4, -20))
+    assert b.path == on.bresenham_path([2, 9], [4, -20]) and b.steep
+
+
+# ------------------------------------------------------------------ Mapping (G2)
+@pytest.mark.parametrize("n", [120, 200, 360])
+def test_mapping_demo_golden(slam, g2, n):
+    m = slam.Mapping(200, 200, 0.1)
+    for i in range(10):
+        c = g2["demo%d_c" % n][i]
+        p = m.update(g2["demo%d_ox" % n][i], g2["demo%d_oy" % n][i], c[0], c[1])
+        assert p is m.pmap and p.dtype == np.float64
+        assert np.array_equal(p.astype(np.int8), g2["demo%d_pmap_steps" % n][i]), i
+    assert np.max(np.abs(m.datamap - g2["demo%d_datamap" % n])) < 1e-9
+
+
+def test_mapping_static_centre_golden(slam, g2):
+    m = slam.Mapping(200, 200, 0.1)
+    c = g2["static_c"]
+    for i in range(5):
+        p = m.update(g2["static_ox"][i], g2["static_oy"][i], np.array([c[0]]), np.array([c[1]]))
+        assert np.array_equal(p.astype(np.int8), g2["static_pmap_steps"][i]), i
+    assert np.max(np.abs(m.datamap - g2["static_datamap"])) < 1e-9
+
+
+@pytest.mark.parametrize("case,xw,yw", [("edge", 200, 200), ("outside", 200, 200), ("rect", 120, 260)])
+def test_mapping_cases_golden(slam, g2, case, xw, yw):
+    m = slam.Mapping(xw, yw, 0.1)
+    c = g2[case + "_c"]
+    p = m.update(g2[case + "_ox"], g2[case + "_oy"], c[0], c[1])
+    assert np.array_equal(p.astype(np.int8), g2[case + "_pmap"])
+    assert np.max(np.abs(m.datamap - g2[case + "_datamap"])) < 1e-9
+    og = co.Grid(xw, yw)
+    og.update(g2[case + "_ox"], g2[case + "_oy"], c[0], c[1])
+    ps, ht = m.counters()
+    assert np.array_equal(ps, og.pass_cnt) and np.array_equal(ht, og.hit_cnt)
+    assert m.visits() == og.visits
+    assert np.array_equal(m.occupancy_grid_data(), og.occupancy_grid_data())
+
+
+def test_mapping_errors_like_int(slam):
+    m = slam.Mapping(200, 200, 0.1)
+    with pytest.raises(ValueError):
+        m.update(np.array([1.0, np.nan]), np.array([0.0, 0.0]), 0.0, 0.0)
+    with pytest.raises(OverflowError):
+        m.update(np.array([1.0]), np.array([np.inf]), 0.0, 0.0)
+    with pytest.raises(ValueError):
+        m.update(np.array([1.0]), np.array([1.0]), np.nan, 0.0)
+    m = slam.Mapping(200, 200, 0.1)
+    p = m.update(np.array([np.inf, np.inf]), np.array([np.nan, 1.0]), np.nan, 0.0)   # every beam skipped: no error
+    assert np.all(p == 50)
+    with pytest.raises(OverflowError):
+        m.update(np.array([1.0e9]), np.array([0.0]), 0.0, 0.0)                     # beyond the 2^20-cell ray limit
+    p = m.update(np.array([0.5]), np.array([0.0]), 0.0, 0.0)                       # still usable afterwards
+    assert p[105, 100] == 100 and p[100, 100] == 0 and np.sum(p != 50) == 6
+
+
+def test_mapping_pass_threshold_1001(slam):
+    """The 1001st pass flips a never-hit cell to occupied (sequential float64 sum)."""
+    g = slam.DeviceGrid(1, 200, 200, 10.0, 10.0, 10.0)
+    ox = np.full((250, 4), 0.55)
+    for rep in range(1, 5):
+        g.update_host(ox, np.zeros_like(ox), np.zeros(250), np.zeros(250))
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert r["pass"][101, 100] == 1000 * rep and r["hit"][105, 100] == 1000 * rep
+        assert r["pmap"][101, 100] == (0 if rep == 1 else 100)
+    g.update_host(ox[:1, :1] * 0 + 0.15, np.zeros((1, 1)), np.zeros(1), np.zeros(1))
+    assert g.read(0)["pmap"][100, 100] == 100
+
+
+def test_generalised_index_rule_vs_oracle(slam, syn):
+    """400x400 @ 0.05 (scale 20, offset 10) and 2000x2000 @ 0.02 (50, 20): cfg2 / cfg5 grids."""
+    rng = np.random.default_rng(5)
+    for (xw, reso, rmax) in ((400, 0.05, 9.0), (2000, 0.02, 22.0)):
+        g = slam.DeviceGrid.metric(1, xw, xw, reso)
+        s = 1.0 / reso
+        og = co.Grid(xw, xw, round(s), xw / (2 * round(s)), xw / (2 * round(s)))
+        for _ in range(3):
+            ang = np.linspace(-np.pi, np.pi, 360)
+            d = rng.random(360) * rmax + 0.3
+            c = rng.uniform(-2, 2, size=2)
+            ox, oy = c[0] + np.cos(ang) * d, c[1] + np.sin(ang) * d
+            g.update_host(ox, oy, c[0], c[1])
+            og.update(ox, oy, c[0], c[1])
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+        assert np.array_equal(r["pmap"], og.pmap) and g.visits() == og.visits
+
+
+# ------------------------------------------------------------------ ICP (G3)
+def test_laser_to_numpy_golden(slam, g3):
+    icp = slam.ICP()
+    for k in range(int(g3["nn_count"])):
+        r = g3["nn%d_ranges" % k]
+        pc = slam.scan_to_pc(Msg(r[1]), clip_inf=True)
+        assert np.array_equal(pc, g3["nn%d_src" % k])
+        assert np.array_equal(icp.laserToNumpy(Msg(r[0])), g3["nn%d_tar" % k])   # no inf in these scans
+    r = np.array([1.0, np.inf, 2.0], dtype=np.float32)
+    assert np.hypot(*slam.scan_to_pc(Msg(r), clip_inf=True)[:2, 1]) == 30.0
+    assert not np.isfinite(icp.laserToNumpy(Msg(r))[0, 1])
+
+
+def test_find_nearest_golden(slam, g3):
+    icp = slam.ICP()
+    for k in range(int(g3["nn_count"])):
+        tar, src = g3["nn%d_tar" % k], g3["nn%d_src" % k]
+        d, i = icp.findNearest(src[:2, :].transpose(), tar[:2, :].transpose())
+        assert i.dtype == np.int64 and np.array_equal(i, g3["nn%d_idx" % k])
+        assert np.max(np.abs(d - g3["nn%d_dist" % k])) < 1e-14
+
+
+def test_find_nearest_ties_nan_and_sizes(slam):
+    icp = slam.ICP()
+    tar = np.array([[1.0, 0.0], [-1.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    src = np.array([[0.0, 0.0], [np.nan, 0.0], [1.0, 0.0]])
+    d, i = icp.findNearest(src, tar)
+    assert list(i) == [0, 0, 0] and list(d) == [1.0, 0.0, 0.0]
+    rng = np.random.default_rng(1)
+    for n, m in ((1, 1), (5, 700), (1500, 3), (777, 1081)):
+        s, t = rng.normal(size=(n, 2)), rng.normal(size=(m, 2))
+        d, i = icp.findNearest(s, t)
+        dd, ii = co.find_nearest(s, t)
+        assert np.array_equal(i, ii) and np.max(np.abs(d - dd)) < 1e-14
+
+
+def test_get_transform_golden(slam, g3):
+    icp = slam.ICP()
+    for k in range(100):
+        a, b = g3["gt_src"][k], g3["gt_tar"][k]
+        n = int(np.sum(~np.isnan(a[:, 0])))
+        T = icp.getTransform(a[:n], b[:n])
+        assert np.max(np.abs(T - g3["gt_T"][k])) < FTOL, (k, bool(g3["gt_reflect"][k]))
+
+
+def test_icp_process_golden(slam, g3):
+    icp = slam.ICP()
+    for k in range(g3["pr_T"].shape[0]):
+        n = int(g3["pr_n"][k])
+        mi, tol = int(g3["pr_cfg"][k, 0]), float(g3["pr_cfg"][k, 1])
+        tar = slam.scan_to_pc(Msg(g3["pr_ranges"][k, 0, :n]), clip_inf=True)
+        src = slam.scan_to_pc(Msg(g3["pr_ranges"][k, 1, :n]), clip_inf=True)
+        slam.param.set_param('/icp/tolerance', tol)
+        icp.max_iter = mi
+        try:
+            T = icp.process(tar, src)
+        finally:
+            slam.param.clear_params()
+        assert icp.last_iters == g3["pr_iters"][k], k
+        assert np.max(np.abs(T - g3["pr_T"][k])) < FTOL, k
+        assert abs(icp.last_mean_error - g3["pr_mean_err"][k]) < FTOL
+
+
+def test_icp_ragged_golden(slam, g3):
+    icp = slam.ICP()
+    tar = slam.scan_to_pc(Msg(g3["rag_r0"]), clip_inf=True)
+    src = slam.scan_to_pc(Msg(g3["rag_r1"]), clip_inf=True)
+    T = icp.process(tar, src)
+    assert icp.last_iters == int(g3["rag_iters"]) and np.max(np.abs(T - g3["rag_T"])) < FTOL
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (63, 64), (65, 129), (1080, 1080), (1500, 900), (2500, 700), (5000, 64)])
+def test_icp_batch_sizes_vs_oracle(slam, n, m):
+    """Edge sizes incl. more than one query per lane (n > 1024) and tiny clouds."""
+    rng = np.random.default_rng(n * 7 + m)
+    B = 3
+    tar = rng.normal(0, 3, size=(B, 2, m))
+    th = rng.uniform(-0.1, 0.1, size=B)
+    src = np.empty((B, 2, n))
+    for b in range(B):
+        pick = rng.integers(0, m, size=n)
+        c, s = np.cos(th[b]), np.sin(th[b])
+        x, y = tar[b, 0, pick] + rng.normal(0, 0.02, n), tar[b, 1, pick] + rng.normal(0, 0.02, n)
+        src[b, 0], src[b, 1] = c * x - s * y + 0.05, s * x + c * y - 0.03
+    T, it, err = slam.icp_batch_host(tar, src, 12, 1e-4)
+    oT, oit, oerr = co.icp_batch(tar, src, 12, 1e-4)
+    assert np.array_equal(it, oit)
+    assert np.max(np.abs(T - oT)) < FTOL and np.max(np.abs(err - oerr)) < FTOL
+
+
+def test_icp_max_iter_zero_and_tol_zero(slam, syn):
+    pair = syn.scan_pair(120, seed=1)
+    tar, src = co.laser_to_points(pair.ranges[0], AMIN, AMAX), co.laser_to_points(pair.ranges[1], AMIN, AMAX)
+    tar, src = np.array(tar)[None], np.array(src)[None]
+    for mi, tol in ((0, 0.001), (1, 0.0), (10, 0.0)):
+        T, it, _ = slam.icp_batch_host(tar, src, mi, tol)
+        oT, oit, _ = co.icp_batch(tar, src, mi, tol)
+        assert it[0] == oit[0] == mi and np.max(np.abs(T - oT)) < FTOL
+
+
+@pytest.mark.parametrize("dtype,npdt", [("f32", np.float32), ("f16", np.float16)])
+def test_icp_reduced_storage_matches_oracle_on_rounded_points(slam, syn, dtype, npdt):
+    """f32 / f16 are STORAGE types of the point buffers; arithmetic stays float64, so the
+    result must equal the oracle fed the same rounded points."""
+    rep = syn.make_replay(9, 360, seed=12)
+    pts = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges]).astype(npdt)
+    tar, src = pts[:-1], pts[1:]
+    T, it, err = slam.icp_batch_host(tar, src, 30, 0.001, dtype=dtype)
+    oT, oit, oerr = co.icp_batch(tar.astype(np.float64), src.astype(np.float64), 30, 0.001)
+    assert np.array_equal(it, oit) and np.max(np.abs(T - oT)) < FTOL
+    # and the device conversion rounds exactly like NumPy's
+    dev = np.empty((2, 360), dtype=npdt)
+    ct, st = slam._abi.trig_tables(AMIN, AMAX, 360)
+    r0 = np.ascontiguousarray(rep.ranges[0])
+    slam._abi.check(slam._abi.lib().slam_scan_to_points(slam.default_context().handle, r0.ctypes.data, ct.ctypes.data,
+                                                       st.ctypes.data, 1, 360, 1, slam._abi.DTYPES[dtype], dev.ctypes.data))
+    assert np.array_equal(dev, pts[0])
+
+
+def test_particle_priors_vs_oracle(slam, syn):
+    """cfg3 operator: one scan pair, P perturbed priors (shared target and source)."""
+    pair = syn.scan_pair(360, seed=2)
+    tar = np.array(co.laser_to_points(pair.ranges[0], AMIN, AMAX))
+    src = np.array(co.laser_to_points(pair.ranges[1], AMIN, AMAX))
+    pri = syn.particle_priors(64, seed=2)
+    mats = np.zeros((64, 2, 3))
+    mats[:, 0, 0], mats[:, 0, 1], mats[:, 0, 2] = np.cos(pri[:, 2]), -np.sin(pri[:, 2]), pri[:, 0]
+    mats[:, 1, 0], mats[:, 1, 1], mats[:, 1, 2] = np.sin(pri[:, 2]), np.cos(pri[:, 2]), pri[:, 1]
+    T, it, err = slam.icp_batch_host(tar, src, 30, 0.001, prior=mats)
+    srcs = np.stack([np.stack([m[0, 0] * src[0] + m[0, 1] * src[1] + m[0, 2], m[1, 0] * src[0] + m[1, 1] * src[1] + m[1, 2]])
+                     for m in mats])
+    oT, oit, oerr = co.icp_batch(np.repeat(tar[None], 64, 0), srcs, 30, 0.001)
+    assert np.array_equal(it, oit) and np.max(np.abs(T - oT)) < FTOL
+    assert len(set(it.tolist())) > 1   # the batch really holds different solves
+
+
+def test_pose_compose_vs_oracle(slam):
+    rng = np.random.default_rng(3)
+    L, n = 3, 2500     # longer than one 1024-step chunk
+    th = rng.uniform(-0.1, 0.1, size=(L, n))
+    T = np.zeros((L, n, 9))
+    T[..., 0], T[..., 1], T[..., 2] = np.cos(th), -np.sin(th), rng.normal(0, 0.05, (L, n))
+    T[..., 3], T[..., 4], T[..., 5] = np.sin(th), np.cos(th), rng.normal(0, 0.05, (L, n))
+    T[..., 8] = 1
+    p0 = rng.normal(size=(L, 3))
+    out = np.empty((L, n, 3))
+    A = slam._abi
+    A.check(A.lib().slam_pose_compose(slam.default_context().handle, T.ctypes.data, p0.ctypes.data, L, n, out.ctypes.data))
+    for l in range(L):
+        s = p0[l].copy()
+        for k in range(n):
+            s = co.compose_pose(s, T[l, k].reshape(3, 3))
+            assert np.max(np.abs(out[l, k] - s)) < 1e-10, (l, k)
+
+
+# ------------------------------------------------------------------ pipeline (G4)
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_pipeline_golden_fused(slam, g4, tag):
+    ranges = g4[tag + "_ranges"]
+    grid = slam.DeviceGrid(1, 200, 200, 10.0, 10.0, 10.0)
+    poses, T, it = slam.replay_host(ranges, AMIN, AMAX, grid=grid)
+    assert np.max(np.abs(poses - g4[tag + "_poses"])) < FTOL
+    assert np.max(np.abs(T - g4[tag + "_T"])) < FTOL
+    r = grid.read(0, want=("pmap", "datamap"))
+    assert np.array_equal(r["pmap"], g4[tag + "_pmap"])
+    assert np.max(np.abs(r["datamap"] - g4[tag + "_datamap"])) < 1e-9
+    assert np.array_equal(grid.occupancy_grid_data(0), g4[tag + "_grid_data"])
+
+
+def test_pipeline_golden_node_callbacks(slam, g4):
+    """The same stream fed message by message through the SLAM_EKF shim (decimation: every
+    5th message is processed, slam_ekf.py:65-68)."""
+    ranges = g4["a_ranges"]
+    node = slam.SLAM_EKF()
+    k_proc = 0
+    for k in range(ranges.shape[0]):
+        for rep in range(5):   # 4 dropped + 1 processed
+            node.laserCallback(Msg(ranges[k]))
+        if k >= 1:
+            assert np.max(np.abs(node.xEst[:3, 0] - g4["a_poses"][k - 1])) < FTOL, k
+            k_proc += 1
+    assert k_proc == ranges.shape[0] - 1
+    assert np.array_equal(node.mapping.pmap.astype(np.int8), g4["a_pmap"])
+    assert np.array_equal(node.last_map["data"], g4["a_grid_data"])
+    assert node.last_map["width"] == 200 and node.last_map["origin"][:2] == (-10.0, -10.0)
+
+
+def test_w7_node_callbacks_vs_oracle(slam, syn):
+    """W7 ICP.laserCallback: first scan = target, then every 6th message (icp.py:51-54),
+    launch-file parameters max_iter=10 / tolerance=0 (W7/launch/icp.launch:10-11)."""
+    rep = syn.make_replay(31, 120, seed=8)
+    slam.param.set_param('/icp/max_iter', 10)
+    slam.param.set_param('/icp/tolerance', 0)
+    try:
+        icp = slam.ICP()
+    finally:
+        slam.param.clear_params()
+    sta = [0.0, 0.0, 0.0]
+    prev = on.laser_to_numpy(rep.ranges[0], AMIN, AMAX)
+    for k in range(31):
+        icp.laserCallback(Msg(rep.ranges[k]))
+        if k > 0 and k % 6 == 0:
+            cur = on.laser_to_numpy(rep.ranges[k], AMIN, AMAX)
+            T, it, _ = co.icp_process(prev, cur, 10, 0.0)
+            sta = list(co.compose_pose(sta, T))
+            prev = cur
+            assert icp.last_iters == it == 10
+            assert np.max(np.abs(np.array(icp.sensor_sta) - np.array(sta))) < FTOL, k
+    assert icp.last_odom["position"][2] == 0.001 and icp.last_odom["frame_id"] == "world_base"
+
+
+# ------------------------------------------------------------------ replay vs oracle at larger sizes
+def test_replay_200_scans_vs_oracle(slam, syn):
+    rep = syn.make_replay(200, 360, seed=21, stride=5)
+    grid = slam.DeviceGrid.metric(1, 400, 400, 0.05)
+    poses, T, it = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid)
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    oposes, oT, oit, visits = co.replay(rep.ranges, AMIN, AMAX, og, threads=8)
+    assert np.array_equal(it, oit)
+    assert np.max(np.abs(poses - oposes)) < FTOL and np.max(np.abs(T - oT)) < FTOL
+    r = grid.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+    assert np.array_equal(r["pmap"], og.pmap) and grid.visits() == visits
+
+
+def test_multi_trajectory_replay_and_grid_routing(slam, syn):
+    """L = 3 streams into 2 maps (streams 0 and 2 share map 1): trajectories stay
+    independent, maps add up."""
+    reps = [syn.make_replay(30, 120, seed=30 + l) for l in range(3)]
+    ranges = np.stack([r.ranges for r in reps])
+    grid = slam.DeviceGrid(2, 200, 200, 10.0, 10.0, 10.0)
+    p0 = np.array([[0, 0, 0], [1.0, -1.0, 0.5], [-2.0, 0.5, -1.0]])
+    poses, T, it = slam.replay_host(ranges, AMIN, AMAX, grid=grid, pose0=p0, grid_of_traj=[1, 0, 1])
+    ogs = [co.Grid(200, 200), co.Grid(200, 200)]
+    for l, gi in enumerate([1, 0, 1]):
+        op, oT, oit, _ = co.replay(ranges[l], AMIN, AMAX, ogs[gi], pose0=p0[l])
+        assert np.array_equal(it[l], oit) and np.max(np.abs(poses[l] - op)) < FTOL
+    for gi in range(2):
+        r = grid.read(gi, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], ogs[gi].pass_cnt) and np.array_equal(r["hit"], ogs[gi].hit_cnt)
+        assert np.array_equal(r["pmap"], ogs[gi].pmap)
+
+
+def test_dense_1080_beam_config(slam, syn):
+    """cfg5 shape: 1080 beams (two queries per lane), 2000x2000 @ 0.02 m map, room x2."""
+    rep = syn.make_replay(6, 1080, seed=3, room_scale=2.0)
+    grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02)
+    poses, T, it = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid)
+    og = co.Grid(2000, 2000, 50.0, 20.0, 20.0)
+    oposes, oT, oit, visits = co.replay(rep.ranges, AMIN, AMAX, og, threads=8)
+    assert np.array_equal(it, oit) and np.max(np.abs(poses - oposes)) < FTOL
+    r = grid.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and grid.visits() == visits
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs[1])
+def test_full_size_replay(slam, syn):
+    """BASELINE configs[1] at full size: 1k processed scans (every 5th message of a 10 Hz
+    stream), 360 beams, 400x400 @ 0.05 m, buffers resident in HBM (slam_replay_dev).
+    Compared in full with the C oracle, plus size-independent properties: run-to-run bit
+    identity, exact doubling of the counters under a second accumulation, visit count ==
+    sum of counters."""
+    import torch
+    rep = syn.make_replay(1000, 360, seed=1, stride=5)
+    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX)
+    grid = dr.make_grid(1, 400, 400, 0.05)
+    dr.run()
+    poses1, T1, it1 = dr.results()
+    c1 = grid.read(0, want=("pmap", "pass", "hit"))
+    v1 = grid.visits()
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    oposes, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8)
+    assert np.array_equal(it1[0], oit)
+    assert np.max(np.abs(poses1[0] - oposes)) < FTOL and np.max(np.abs(T1[0] - oT)) < FTOL
+    assert np.array_equal(c1["pass"], og.pass_cnt) and np.array_equal(c1["hit"], og.hit_cnt)
+    assert np.array_equal(c1["pmap"], og.pmap) and v1 == ov
+    dr.run()                       # reset + rerun: identical bits
+    poses2, T2, it2 = dr.results()
+    c2 = grid.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(poses1, poses2) and np.array_equal(T1, T2) and np.array_equal(it1, it2)
+    assert all(np.array_equal(c1[k], c2[k]) for k in c1) and grid.visits() == v1
+    dr.run(reset_grid=False)       # accumulate a second pass: counters double exactly
+    c3 = grid.read(0, want=("pass", "hit"))
+    assert np.array_equal(c3["pass"], 2 * c1["pass"]) and np.array_equal(c3["hit"], 2 * c1["hit"])
+    assert int(c1["pass"].sum()) + int(c1["hit"].sum()) == v1
+    assert set(np.unique(c1["pmap"]).tolist()) <= {0, 50, 100}
+    assert np.array_equal(c1["pmap"] == 50, (c1["pass"] + c1["hit"]) == 0)
+    assert it1.min() >= 2 and it1.max() <= 30
+    torch.cuda.synchronize()
