@@ -90,6 +90,16 @@ def lib():
                 raise LibraryMissing(
                     "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(or `make -C <package>/csrc`). There is no CPU fallback for this path." % LIB_PATH)
+            # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+            # libamdhip64.so.7.  If torch is importable it is loaded FIRST, so that this
+            # library's libamdhip64.so.7 dependency resolves to the copy torch uses and
+            # device pointers / streams can be shared (bench.py, torch.distributed).  Loading
+            # them in the other order leaves torch without a usable device.
+            if os.environ.get("SLAM_HIP_STANDALONE") != "1":
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             L = C.CDLL(LIB_PATH)
             for name, (args, res) in _SIGS.items():
                 fn = getattr(L, name)
