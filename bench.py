@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py - scans/s of the ICP + occupancy-grid hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK /
+  WORLD_SIZE / MASTER_* from the environment).  Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[1]: a 1k-scan replay, 360 beams, ICP.process +
+Mapping.update per scan into a 400x400 @ 0.05 m grid.  "1k scans" are 1000 PROCESSED
+scans: every 5th message of a 10 Hz stream, as the reference's callback decimates
+(W12m/slam_ekf.py:65-68), so consecutive processed scans are 0.5 s apart.  ICP parameters
+are the ones effective in the W12 mapping node, max_iter 30 / tolerance 1e-3
+(W12m/icp.py:21-25).  One "step" = one pass of the hot path over that batch, inputs
+(float32 ranges) already resident in HBM: map reset -> polar->Cartesian -> 999 ICP solves
+-> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of `value`: processed
+scans per second (one ICP.process + one Mapping.update each), summed over all ranks.
+
+With N > 1 every rank replays its own trajectory (seed 1 + rank; weak scaling, no
+data-path collective) and each step ends with one RCCL all_gather of the ranks' final
+poses (3 float64 each), the only exchange BASELINE.json configs[3] has.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside the
+library on the launch stream) and "cpu_baseline" (oracle/slam_oracle.c, the C port of the
+reference, on this host's cores; rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd"
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector (half the 157.3 TF FP32 vector rate)
+AMIN, AMAX = -3.14159, 3.14159
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scans", type=int, default=1000)
+    ap.add_argument("--beams", type=int, default=360)
+    ap.add_argument("--grid", type=int, default=400)
+    ap.add_argument("--reso", type=float, default=0.05)
+    ap.add_argument("--stride", type=int, default=5)
+    ap.add_argument("--room-scale", type=float, default=1.0)
+    ap.add_argument("--max-iter", type=int, default=30)
+    ap.add_argument("--tol", type=float, default=1e-3)
+    ap.add_argument("--points", default="f64", choices=["f64", "f32", "f16"],
+                    help="storage type of the ICP point buffers (arithmetic is always f64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--check", action="store_true", help="also compare the GPU result with the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(rep, args, budget_s):
+    """The C port of the reference (oracle/slam_oracle.c, orc_replay_mt: ICP solves and ray
+    casting under OpenMP) on this host, same replay, repeated until ~budget_s seconds."""
+    from oracle import c_oracle as co
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    s = round(1.0 / args.reso)
+    reps, t_used = 0, 0.0
+    while reps < 1 or (t_used < budget_s and reps < 40):
+        g = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
+        t0 = time.perf_counter()
+        co.replay(rep.ranges, AMIN, AMAX, g, max_iter=args.max_iter, tolerance=args.tol, threads=threads, mt_grid=True)
+        t_used += time.perf_counter() - t0
+        reps += 1
+    scans = (rep.ranges.shape[0] - 1) * reps
+    return {"value": scans / t_used, "unit": "scans/s", "cores": threads, "kind": "port",
+            "sample": "full %d-scan replay x %d repeats (%.1f s), C port of the reference, OpenMP over scan pairs and rays"
+                      % (rep.ranges.shape[0], reps, t_used)}
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+        return d.get(kernel, {}).get("hbm_bytes_per_launch"), d.get(kernel, {}).get("source")
+    except Exception:
+        return None, None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    slam = importlib.import_module(PKG)
+
+    rep = slam.synthetic.make_replay(args.scans, args.beams, seed=1 + rank, room_scale=args.room_scale, stride=args.stride)
+    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol, dtype=args.points, device=local)
+    grid = dr.make_grid(1, args.grid, args.grid, args.reso)
+    pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=dr.dev)
+    gathered = torch.empty((world, 3), dtype=torch.float64, device=dr.dev) if world > 1 else None
+    L = slam._abi.lib()
+
+    def step():
+        dr.run(reset_grid=True)
+        slam._abi.check(L.slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, dr.poses[0, -1].contiguous())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    dr.ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    fam = dr.ctx.timing_read()
+    dr.ctx.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dr.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    scans_per_step = dr.scans_per_run
+    visits = grid.visits()                 # in-bounds cell visits of the last step (reset every step)
+    poses, T, iters = dr.results()
+    total_scans = scans_per_step * world * args.steps
+    value = total_scans / elapsed
+
+    # ---- roofline of the dominant kernel (largest share of the HIP-event time) -----------
+    ms = {k: v[0] for k, v in fam.items() if v[1] > 0}
+    dom = max(ms, key=ms.get)
+    dom_ms, dom_n = fam[dom]
+    avg_s = dom_ms / dom_n * 1e-3
+    psz = {"f64": 8, "f32": 4, "f16": 2}[args.points]
+    icp_bytes = scans_per_step * ((2 * args.beams) * 2 * psz + 72)        # (n_src+n_tar)*2*s + 72 per scan
+    grid_bytes = 9 * visits                                               # 9 B per in-bounds cell visit
+    alg_bytes = {"icp": icp_bytes, "grid": grid_bytes,
+                 "points": scans_per_step * args.beams * (4 + 2 * psz), "compose": scans_per_step * (72 + 24),
+                 "finalize": args.grid * args.grid * 9}.get(dom, 0)
+    kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "points": "k_scan_to_points", "compose": "k_pose_compose",
+             "finalize": "k_grid_finalize"}.get(dom, dom)
+    traffic, tsrc = load_traffic(kname)
+    achieved = alg_bytes / avg_s / 1e9
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_ms": dom_ms / dom_n, "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms_per_step": {k: fam[k][0] / args.steps for k in ms}}
+    evals = float(iters.astype(np.int64).sum()) * args.beams * args.beams   # distance evaluations per step
+    icp_s = fam["icp"][0] / max(fam["icp"][1], 1) * 1e-3
+    roofline["icp_valu"] = {"distance_evals_per_s": evals / icp_s, "flop_per_eval": 6,
+                            "achieved_tflops_f64": evals * 6 / icp_s / 1e12, "peak_tflops_f64": F64_VALU_PEAK_TFLOPS,
+                            "frac": evals * 6 / icp_s / 1e12 / F64_VALU_PEAK_TFLOPS, "mean_iters": float(iters.mean())}
+    grid_s = fam["grid"][0] / max(fam["grid"][1], 1) * 1e-3
+    roofline["grid_atomics"] = {"cell_visits_per_step": visits, "visits_per_s": visits / grid_s if grid_s else None}
+
+    out = {
+        "metric": "scans/sec (360-beam ICP + 0.05 m grid update)", "value": value, "unit": "scans/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d-scan replay (every %dth message of a 10 Hz stream), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid"
+                               % (args.scans, args.stride, args.beams, args.max_iter, args.tol, args.grid, args.grid, args.reso),
+                   "scans_per_step_per_gpu": scans_per_step, "point_buffers": args.points, "trajectories_per_gpu": 1,
+                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses per step" if world > 1 else "")},
+        "roofline": roofline,
+    }
+    if args.check and rank == 0:
+        from oracle import c_oracle as co
+        s = round(1.0 / args.reso)
+        og = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
+        op, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, max_iter=args.max_iter, tolerance=args.tol,
+                                    threads=os.cpu_count() or 1, mt_grid=True)
+        out["parity"] = {"pose_max_abs_err": float(np.max(np.abs(poses[0] - op))), "iters_equal": bool(np.array_equal(iters[0], oit)),
+                         "pmap_cell_mismatches": int(np.sum(pmap.cpu().numpy() != og.pmap)), "visits_equal": bool(visits == ov)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rep, args, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,8 @@ def lib():
         L.orc_occupancy_grid_data.argtypes = [C.c_void_p, _bp]
         L.orc_replay.argtypes = [_fp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_double, _dp, C.c_void_p, _dp, _dp, _ip, C.c_int]
         L.orc_replay.restype = C.c_long
+        L.orc_replay_mt.argtypes = L.orc_replay.argtypes
+        L.orc_replay_mt.restype = C.c_long
         _LIB = L
     return _LIB
 
@@ -162,14 +164,16 @@ def pass_count_threshold(free_inc=0.01, thresh=10.0):
     return lib().orc_pass_count_threshold(free_inc, thresh)
 
 
-def replay(ranges, angle_min, angle_max, grid=None, max_iter=30, tolerance=0.001, pose0=(0.0, 0.0, 0.0), threads=1):
-    """ranges float32 [n_scan, n] -> (poses [n_scan-1,3], T [n_scan-1,3,3], iters, visits)."""
+def replay(ranges, angle_min, angle_max, grid=None, max_iter=30, tolerance=0.001, pose0=(0.0, 0.0, 0.0), threads=1,
+           mt_grid=False):
+    """ranges float32 [n_scan, n] -> (poses [n_scan-1,3], T [n_scan-1,3,3], iters, visits).
+    mt_grid=True uses orc_replay_mt (rays cast in parallel into the integer counters; no datamap)."""
     r = _c(ranges, np.float32)
     n_scan, n = r.shape
     ct, st = trig_tables(angle_min, angle_max, n)
     poses, T, it = np.empty((n_scan - 1, 3)), np.empty((n_scan - 1, 9)), np.empty(n_scan - 1, dtype=np.int32)
-    v = lib().orc_replay(r, n_scan, n, _c(ct), _c(st), max_iter, tolerance, _c(pose0), grid._g if grid else None,
-                         poses, T, it, threads)
+    fn = lib().orc_replay_mt if mt_grid else lib().orc_replay
+    v = fn(r, n_scan, n, _c(ct), _c(st), max_iter, tolerance, _c(pose0), grid._g if grid else None, poses, T, it, threads)
     if grid is not None:
         grid.visits += v
     return poses, T.reshape(-1, 3, 3), it, v

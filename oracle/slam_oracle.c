@@ -339,3 +339,83 @@ long orc_replay(const float *ranges, int n_scan, int n, const double *cos_t, con
     free(px); free(py); free(ox); free(oy);
     return visits;
 }
+
+/* Counters-only, OpenMP-parallel ray casting of one scan (used by orc_replay_mt):
+ * the same walk as orc_grid_update, integer evidence only, atomic adds. */
+static long grid_update_counts(orc_grid *g, const double *ox, const double *oy, int n, double cx, double cy)
+{
+    long visits = 0;
+    for (int i = 0; i < n; ++i) {
+        if (isinf(ox[i])) continue;
+        int x1 = (int)(g->scale * (ox[i] + g->off_x)), y1 = (int)(g->scale * (oy[i] + g->off_y));
+        int x0 = (int)(g->scale * (cx + g->off_x)), y0 = (int)(g->scale * (cy + g->off_y));
+        if (x0 == x1 && y0 == y1) continue;
+        int steep = abs(y1 - y0) > abs(x1 - x0);
+        if (steep) { int t = x0; x0 = y0; y0 = t; t = x1; x1 = y1; y1 = t; }
+        int flag = 0;
+        if (x0 > x1) { flag = 1; int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+        int dx = x1 - x0, dy = abs(y1 - y0);
+        double error = 0.0, derr = (double)dy / (double)dx;
+        int y = y0, ystep = y0 < y1 ? 1 : -1;
+        for (int k = 0; k <= dx; ++k) {
+            int x = x0 + k;
+            int lx = steep ? y : x, ly = steep ? x : y;
+            int last = flag ? (k == 0) : (k == dx);
+            if (lx >= 0 && lx < g->xw && ly >= 0 && ly < g->yw) {
+                uint32_t *c = (last ? g->hit_cnt : g->pass_cnt) + (size_t)lx * g->yw + ly;
+#pragma omp atomic
+                *c += 1;
+                ++visits;
+            }
+            error += derr;
+            if (error >= 0.5) { y += ystep; error -= 1.0; }
+        }
+    }
+    return visits;
+}
+
+/* All-cores CPU baseline of the replay for bench.py ("cpu_baseline", kind "port"): ICP
+ * solves in parallel over pairs, poses composed serially, rays cast in parallel over scans
+ * into the integer counters, pmap from the counter rule (pass >= k* or hit >= 1).  Same
+ * results as orc_replay for poses, counters and pmap; datamap is not maintained. */
+long orc_replay_mt(const float *ranges, int n_scan, int n, const double *cos_t, const double *sin_t, int max_iter,
+                   double tol, const double pose0[3], orc_grid *g, double *poses_out, double *T_out,
+                   int32_t *iters_out, int threads)
+{
+    if (threads < 1) threads = 1;
+    size_t np = (size_t)n_scan * n;
+    double *px = (double *)malloc(sizeof(double) * np), *py = (double *)malloc(sizeof(double) * np);
+#pragma omp parallel for num_threads(threads)
+    for (int k = 0; k < n_scan; ++k)
+        orc_laser_to_points(ranges + (size_t)k * n, cos_t, sin_t, n, 1, px + (size_t)k * n, py + (size_t)k * n);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int k = 1; k < n_scan; ++k)
+        iters_out[k - 1] = orc_icp_process(px + (size_t)(k - 1) * n, py + (size_t)(k - 1) * n, n,
+                                           px + (size_t)k * n, py + (size_t)k * n, n, max_iter, tol,
+                                           T_out + 9 * (size_t)(k - 1), 0);
+    double sta[3] = {pose0[0], pose0[1], pose0[2]};
+    for (int k = 1; k < n_scan; ++k) {
+        orc_compose_pose(sta, T_out + 9 * (size_t)(k - 1));
+        memcpy(poses_out + 3 * (size_t)(k - 1), sta, sizeof(sta));
+    }
+    long visits = 0;
+    if (g) {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : visits)
+        for (int k = 1; k < n_scan; ++k) {
+            double *ox = (double *)malloc(sizeof(double) * 2 * (size_t)n), *oy = ox + n;
+            const double *p = poses_out + 3 * (size_t)(k - 1);
+            orc_world_points(p, px + (size_t)k * n, py + (size_t)k * n, n, ox, oy);
+            visits += grid_update_counts(g, ox, oy, n, p[0], p[1]);
+            free(ox);
+        }
+        int kstar = orc_pass_count_threshold(g->free_inc, g->thresh);
+        size_t cells = (size_t)g->xw * g->yw;
+#pragma omp parallel for num_threads(threads)
+        for (size_t c = 0; c < cells; ++c) {
+            uint32_t ps = g->pass_cnt[c], ht = g->hit_cnt[c];
+            g->pmap[c] = (ps | ht) ? ((ht >= 1 || ps >= (uint32_t)kstar) ? 100 : 0) : 50;
+        }
+    }
+    free(px); free(py);
+    return visits;
+}

@@ -236,3 +236,14 @@ def test_c_replay_threads_are_deterministic(g4):
     p1, T1, i1, v1 = co.replay(r, -3.14159, 3.14159, co.Grid(200, 200), threads=1)
     p4, T4, i4, v4 = co.replay(r, -3.14159, 3.14159, co.Grid(200, 200), threads=4)
     assert np.array_equal(p1, p4) and np.array_equal(T1, T4) and np.array_equal(i1, i4) and v1 == v4
+
+
+def test_c_replay_mt_equals_serial(syn):
+    """The all-cores baseline (orc_replay_mt) produces the serial oracle's poses, counters and pmap."""
+    rep = syn.make_replay(40, 120, seed=4, stride=5)
+    g1_, g2_ = co.Grid(400, 400, 20.0, 10.0, 10.0), co.Grid(400, 400, 20.0, 10.0, 10.0)
+    p1, T1, i1, v1 = co.replay(rep.ranges, -3.14159, 3.14159, g1_, threads=1)
+    p2, T2, i2, v2 = co.replay(rep.ranges, -3.14159, 3.14159, g2_, threads=8, mt_grid=True)
+    assert np.array_equal(p1, p2) and np.array_equal(i1, i2) and v1 == v2
+    assert np.array_equal(g1_.pass_cnt, g2_.pass_cnt) and np.array_equal(g1_.hit_cnt, g2_.hit_cnt)
+    assert np.array_equal(g1_.pmap, g2_.pmap)
