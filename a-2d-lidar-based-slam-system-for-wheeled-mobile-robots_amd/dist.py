@@ -1,0 +1,121 @@
+"""Multi-GPU sharding of independent scan streams (BASELINE.json configs[3]).
+
+The path shards by construction: ``T_k`` depends only on scans k-1 and k
+(W12m/slam_ekf.py:109-113) and trajectories never interact, so every rank (one process
+per GPU, ``torch.distributed``; backend "nccl" is RCCL on ROCm) replays its own block of
+trajectories with NO data-path collective.  The single exchange is one ``all_gather`` of
+the final poses (3 float64 per trajectory) so every rank ends with all of them; an
+optional ``all_reduce(SUM)`` merges integer evidence counters when ranks ray-cast into one
+shared map (integer sums commute: the merged map is bit-identical for any rank count).
+
+The compute is injected (``runner``): the product passes the HIP ``DeviceReplay``; the
+CPU gloo tests pass the oracle, so the sharding / gathering logic is exercised without a GPU.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shard_range(n_units, rank, world):
+    """Balanced contiguous block [lo, hi) of ``n_units`` for ``rank`` of ``world``."""
+    base, extra = divmod(int(n_units), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def init(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    (as set by torch.distributed.run).  Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def all_gather_poses(local_poses, n_total, device=None):
+    """local_poses [L_local, 3] (this rank's block, in ``shard_range`` order) ->
+    [n_total, 3] on every rank.  Blocks may differ by one trajectory, so they are padded
+    to the largest block for the fixed-size collective."""
+    import torch
+    import torch.distributed as dist
+    local_poses = np.asarray(local_poses, dtype=np.float64).reshape(-1, 3)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_poses.copy()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = -(-n_total // world)
+    pad = np.zeros((cap, 3))
+    pad[: local_poses.shape[0]] = local_poses
+    t = torch.from_numpy(pad.reshape(-1))
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty(world * cap * 3, dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    out = out.cpu().numpy().reshape(world, cap, 3)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(out[r, : hi - lo])
+    return np.concatenate(rows, axis=0)
+
+
+def all_reduce_counters(pass_cnt, hit_cnt, device=None):
+    """Sum integer evidence counters over ranks (shared-map case)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pass_cnt, hit_cnt
+    outs = []
+    for a in (pass_cnt, hit_cnt):
+        t = torch.from_numpy(np.ascontiguousarray(a).astype(np.int64))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        outs.append(t.cpu().numpy().astype(np.uint32))
+    return outs[0], outs[1]
+
+
+def hip_runner(ranges, angle_min, angle_max, max_iter, tolerance, local_rank):
+    """Default compute: this rank's trajectories on its GPU (DeviceReplay, no map)."""
+    from .replay import DeviceReplay
+    dr = DeviceReplay(ranges, angle_min, angle_max, max_iter=max_iter, tolerance=tolerance, device=local_rank)
+    dr.run()
+    poses, _T, _it = dr.results()
+    return poses
+
+
+def replay_sharded(make_ranges, n_traj, angle_min, angle_max, max_iter=30, tolerance=0.001, runner=hip_runner,
+                   backend=None):
+    """Replay ``n_traj`` independent scan streams over all ranks.
+
+    ``make_ranges(i)`` returns trajectory i's float32 ranges [n_scan, n]; each rank only
+    materialises its own block.  Returns (final_poses [n_traj, 3] on every rank,
+    local_poses [L_local, n_scan-1, 3], (lo, hi))."""
+    rank, world, local = init(backend)
+    lo, hi = shard_range(n_traj, rank, world)
+    if hi > lo:
+        ranges = np.stack([np.asarray(make_ranges(i), dtype=np.float32) for i in range(lo, hi)])
+        poses = np.asarray(runner(ranges, angle_min, angle_max, max_iter, tolerance, local))
+        finals = poses[:, -1, :]
+    else:
+        poses, finals = np.zeros((0, 0, 3)), np.zeros((0, 3))
+    device = None
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            device = torch.device("cuda", local)
+    except Exception:
+        pass
+    return all_gather_poses(finals, n_traj, device=device), poses, (lo, hi)
