@@ -47,6 +47,7 @@ _SIGS = {
     "slam_destroy": ([_vp], _i),
     "slam_synchronize": ([_vp], _i),
     "slam_check_status": ([_vp], _i),
+    "slam_set_option": ([_vp, C.c_char_p, _d], _i),
     "slam_timing_enable": ([_vp, _i], _i),
     "slam_timing_read": ([_vp, _vp, _vp], _i),
     "slam_scan_to_points": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -172,6 +173,9 @@ class Context:
 
     def check_status(self):
         check(lib().slam_check_status(self.handle))
+
+    def set_option(self, name, value):
+        check(lib().slam_set_option(self.handle, name.encode(), float(value)))
 
     def timing_enable(self, on=True):
         check(lib().slam_timing_enable(self.handle, int(bool(on))))

@@ -21,6 +21,10 @@
 // differ from integer Bresenham, so anything else breaks cell parity.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <climits>
+#include <type_traits>
+
 #include "slam_internal.h"
 
 namespace slam {
@@ -207,6 +211,252 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
     hipLaunchKernelGGL(k_grid_update_replay, dim3(n_scan - 1, L), dim3(ray_block(n)), 0, s, g, ranges, cos_t, sin_t,
                        poses, n_scan, n, got);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// LDS-window ray casting (DESIGN.md "K4 v2").
+//
+// Direct global atomics run at the chip's scattered memory-side atomic rate (~2e10 /s,
+// measured: profiles/r01_v1_*), far below what the walks themselves cost.  All rays of a
+// scan start in the same cell and consecutive scans of a stream overlap almost entirely,
+// so one workgroup takes a GROUP of consecutive scans of one stream, accumulates their
+// evidence in a window of the map held in LDS (up to 36,864 cells = 144 KiB of the CU's
+// 160 KiB; one packed uint32 per cell: pass count in bits 0-19, hit count in bits 20-31,
+// ds_add_u32), and flushes the non-zero cells once, row by row, so the global atomics
+// that remain are few and address-contiguous.  The window is the bounding box of the
+// group's ray origins and endpoints (clamped to the map) when that fits, else a
+// sub-rectangle of it around the first origin; cells of a ray outside the window fall
+// back to direct global atomics, so the result is exact for any window.
+// ---------------------------------------------------------------------------------
+constexpr int kWinCells = 36864;     // 144 KiB of LDS
+constexpr int kWinMaxGroup = 64;     // scans per workgroup
+constexpr unsigned kHitShift = 20;   // needs group_size * n < 4096 hits and < 2^20 passes per cell
+
+struct ScanConst {
+    double px, py, c, s;   // ray origin (world) and heading cos / sin (replay source only)
+    int pcx, pcy, cbad, pad;
+};
+
+// Source of rays: scans of a replay (ranges + poses) ...
+struct ReplaySource {
+    const float *ranges;
+    const double *cos_t, *sin_t, *poses;
+    int n_scan, n;
+    __device__ int scans_per_traj() const { return n_scan - 1; }
+    __device__ void scan_const(int l, int k, const GridDev &g, ScanConst &sc) const
+    {
+        const double *pose = poses + 3 * ((size_t)l * (n_scan - 1) + k);
+        sc.px = pose[0]; sc.py = pose[1];
+        sc.c = cos(pose[2]); sc.s = sin(pose[2]);
+        sc.cbad = 0;
+        sc.pcx = to_cell(sc.px, g.scale, g.off_x, sc.cbad);
+        sc.pcy = to_cell(sc.py, g.scale, g.off_y, sc.cbad);
+    }
+    // false: beam skipped (mapping.py:30) or flagged in `bad`
+    __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    {
+        double rr = (double)ranges[((size_t)l * n_scan + k + 1) * n + i];
+        if (rr == INFINITY) rr = 30.0;                               // slam_ekf.py:119
+        double lx = cos_t[i] * rr, ly = sin_t[i] * rr;               // :122
+        double x = sc.c * lx + (-sc.s) * ly + sc.px * 1.0;           // u2T(pose).dot(pc), :89
+        double y = sc.s * lx + sc.c * ly + sc.py * 1.0;
+        if (fabs(x) == INFINITY) return false;
+        pox = to_cell(x, g.scale, g.off_x, bad);
+        poy = to_cell(y, g.scale, g.off_y, bad);
+        bad |= sc.cbad;
+        return !bad;
+    }
+};
+
+// ... or explicit world-frame endpoints (Mapping.update's own arguments).
+struct ExplicitSource {
+    const double *ox, *oy, *cx, *cy;
+    int B, n;
+    __device__ int scans_per_traj() const { return B; }
+    __device__ void scan_const(int, int k, const GridDev &g, ScanConst &sc) const
+    {
+        sc.px = cx[k]; sc.py = cy[k]; sc.c = 1.0; sc.s = 0.0;
+        sc.cbad = 0;
+        sc.pcx = to_cell(sc.px, g.scale, g.off_x, sc.cbad);
+        sc.pcy = to_cell(sc.py, g.scale, g.off_y, sc.cbad);
+    }
+    __device__ bool ray(int, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    {
+        double x = ox[(size_t)k * n + i], y = oy[(size_t)k * n + i];
+        if (fabs(x) == INFINITY) return false;                       // mapping.py:30
+        pox = to_cell(x, g.scale, g.off_x, bad);
+        poy = to_cell(y, g.scale, g.off_y, bad);
+        bad |= sc.cbad;
+        return !bad;
+    }
+};
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+template <class Src>
+__global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [kWinMaxGroup]
+    int *box = reinterpret_cast<int *>(smem + kWinMaxGroup * sizeof(ScanConst));          // bbox[4], window[4]
+    unsigned *win = reinterpret_cast<unsigned *>(smem + kWinMaxGroup * sizeof(ScanConst) + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int l = blockIdx.y;
+    const int s0 = blockIdx.x * group_size;
+    const int cnt = min(group_size, src.scans_per_traj() - s0);
+    const int gi = got ? got[l] : 0;
+    uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
+    const int n = src.n, nrays = cnt * n;
+
+    if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
+    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; }
+    __syncthreads();
+
+    // pass 1: bounding box of everything the group's rays can touch
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
+    for (int r = tid; r < nrays; r += blockDim.x) {
+        int s = r / n, i = r - s * n, pox, poy;
+        if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, bad)) {
+            bx0 = min(bx0, min(pox, sc[s].pcx)); bx1 = max(bx1, max(pox, sc[s].pcx));
+            by0 = min(by0, min(poy, sc[s].pcy)); by1 = max(by1, max(poy, sc[s].pcy));
+        }
+    }
+    bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
+    if (lane == 0 && bx0 <= bx1) {
+        atomicMin(&box[0], bx0); atomicMin(&box[1], by0); atomicMax(&box[2], bx1); atomicMax(&box[3], by1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
+        int W = 0, H = 0;
+        if (x0 <= x1 && y0 <= y1) {
+            W = x1 - x0 + 1; H = y1 - y0 + 1;
+            if ((long)W * H > kWinCells) {                           // keep a sub-rectangle around the first origin
+                int Hd = min(H, 192), Wd = min(W, kWinCells / Hd);
+                int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
+                x0 = cx0; y0 = cy0; W = Wd; H = Hd;
+            }
+        }
+        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H;
+    }
+    __syncthreads();
+    const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
+    for (int w = tid; w < W * H; w += blockDim.x) win[w] = 0u;
+    __syncthreads();
+
+    // pass 2: walk the rays (the reference's float-error Bresenham, see cast_ray)
+    unsigned nvis = 0;
+    for (int r = tid; r < nrays; r += blockDim.x) {
+        int s = r / n, i = r - s * n, pox, poy, b2 = 0;
+        if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
+        Ray ry;
+        if (!ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry)) continue;
+        double error = 0.0;
+        int y = ry.y0;
+        for (int k = 0; k <= ry.dx; ++k) {
+            int x = ry.x0 + k;
+            int lx = ry.steep ? y : x, ly = ry.steep ? x : y;
+            bool last = ry.flag ? (k == 0) : (k == ry.dx);
+            if ((unsigned)lx < (unsigned)g.xw && (unsigned)ly < (unsigned)g.yw) {      // mapping.py:41
+                ++nvis;
+                unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
+                if (wx < (unsigned)W && wy < (unsigned)H) {
+                    atomicAdd(&win[wx * H + wy], last ? (1u << kHitShift) : 1u);
+                } else {
+                    size_t c = (size_t)lx * g.yw + ly;
+                    atomicAdd(last ? &hit[c] : &pass[c], 1u);
+                }
+            }
+            error += ry.derr;                                                        // bresenham.py:51
+            if (error >= 0.5) { y += ry.ystep; error -= 1.0; }                       // :53-55
+        }
+    }
+    __syncthreads();
+
+    // flush: one wave per window row, lanes along y (contiguous in the [x][y] map)
+    for (int row = wave; row < W; row += nwaves) {
+        size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
+        for (int yy = lane; yy < H; yy += kWave) {
+            unsigned v = win[row * H + yy];
+            unsigned p = v & ((1u << kHitShift) - 1u), h = v >> kHitShift;
+            if (p) atomicAdd(&pass[gbase + yy], p);
+            if (h) atomicAdd(&hit[gbase + yy], h);
+        }
+    }
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if (lane == 0) {
+        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
+        if (anybad) atomicOr(g.status, anybad);
+    }
+}
+
+template <class Src>
+static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
+                             hipStream_t s)
+{
+    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + (size_t)kWinCells * 4;
+    static bool attr_done[2] = {false, false};
+    constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
+    if (!attr_done[which]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_win<Src>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[which] = true;
+    }
+    int groups = (scans + group - 1) / group;
+    long rays = (long)group * n;
+    int threads = rays >= 1024 ? 1024 : (int)(((rays + kWave - 1) / kWave) * kWave);
+    if (threads < 256) threads = 256;
+    hipLaunchKernelGGL((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got);
+    return hipGetLastError();
+}
+
+// group == 0: automatic (aim for >= 512 workgroups, at most 16 scans each).
+static int pick_group(int group, long total_scans, int scans_per_traj, int n)
+{
+    int gmax = std::min(kWinMaxGroup, 4095 / std::max(n, 1));
+    if (gmax < 1) return 0;                                          // n too large for the packed counters
+    if (group <= 0) {
+        long want = (total_scans + 511) / 512;
+        group = (int)std::min<long>(std::max<long>(want, 1), 16);
+    }
+    group = std::min(std::min(group, gmax), std::max(scans_per_traj, 1));
+    return group;
+}
+
+hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const double *oy, const double *cx, const double *cy,
+                                  int B, int n, int group, hipStream_t s)
+{
+    int G = pick_group(group, B, B, n);
+    if (G == 0) return launch_grid_update(g, ox, oy, cx, cy, B, n, nullptr, s);
+    ExplicitSource src{ox, oy, cx, cy, B, n};
+    return launch_win(g, src, 1, B, n, G, nullptr, s);
+}
+
+hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                         const double *poses, int L, int n_scan, int n, const int32_t *got, int group,
+                                         hipStream_t s)
+{
+    if (n_scan < 2) return hipSuccess;
+    int G = pick_group(group, (long)L * (n_scan - 1), n_scan - 1, n);
+    if (G == 0) return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n};
+    return launch_win(g, src, L, n_scan - 1, n, G, got, s);
 }
 
 // mapping.py:47-50 applied to the integer counters (see the header comment).

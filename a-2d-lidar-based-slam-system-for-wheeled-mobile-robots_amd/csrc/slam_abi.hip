@@ -76,6 +76,8 @@ struct slam_ctx {
     std::vector<Pending> pending;
     double ms[SLAM_K_COUNT] = {0};
     int64_t launches[SLAM_K_COUNT] = {0};
+    int grid_mode = 1;    // 0: direct global atomics, 1: LDS window
+    int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
 };
 
 struct slam_grid {
@@ -249,6 +251,16 @@ int slam_check_status(slam_ctx *c)
 {
     TRY(use(c));
     return check_status_sync(c);
+}
+
+int slam_set_option(slam_ctx *c, const char *name, double value)
+{
+    TRY(use(c));
+    REQUIRE(name, "null name");
+    if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1, "grid_mode is 0 or 1"); c->grid_mode = (int)value; }
+    else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
+    else return fail(SLAM_ERR_INVALID, "unknown option %s", name);
+    return SLAM_OK;
 }
 
 int slam_timing_enable(slam_ctx *c, int on)
@@ -538,7 +550,10 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     REQUIRE(g && ox && oy && cx && cy, "null pointer");
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
     Timed t(c, SLAM_K_GRID);
-    HIPCHK(launch_grid_update(g->d, ox, oy, cx, cy, B, n, grid_of_batch, c->stream));
+    if (c->grid_mode == 1 && !grid_of_batch)
+        HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream));
+    else
+        HIPCHK(launch_grid_update(g->d, ox, oy, cx, cy, B, n, grid_of_batch, c->stream));
     return SLAM_OK;
 }
 
@@ -698,7 +713,11 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
     }
     if (grid) {
         Timed t(c, SLAM_K_GRID);
-        HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
+        if (c->grid_mode == 1)
+            HIPCHK(launch_grid_update_replay_win(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj,
+                                                 c->grid_group, c->stream));
+        else
+            HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
     }
     return SLAM_OK;
 }

@@ -55,6 +55,13 @@ hipError_t launch_grid_update(const GridDev &g, const double *ox, const double *
 hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, const double *cos_t,
                                      const double *sin_t, const double *poses, int L, int n_scan, int n,
                                      const int32_t *grid_of_traj, hipStream_t s);
+// LDS-window variants (group = scans per workgroup, 0 = automatic); they fall back to the
+// direct-atomic kernels when a scan has too many beams for the packed window counters.
+hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const double *oy, const double *cx,
+                                  const double *cy, int B, int n, int group, hipStream_t s);
+hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t,
+                                         const double *sin_t, const double *poses, int L, int n_scan, int n,
+                                         const int32_t *grid_of_traj, int group, hipStream_t s);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
 hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--points", default="f64", choices=["f64", "f32", "f16"],
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
+    ap.add_argument("--grid-mode", type=int, default=1, help="1: LDS-window ray casting (default), 0: direct global atomics")
+    ap.add_argument("--grid-group", type=int, default=0, help="scans per workgroup in window mode (0: automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", action="store_true", help="also compare the GPU result with the oracle")
@@ -109,6 +111,8 @@ def main():
     rep = slam.synthetic.make_replay(args.scans, args.beams, seed=1 + rank, room_scale=args.room_scale, stride=args.stride)
     dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol, dtype=args.points, device=local)
     grid = dr.make_grid(1, args.grid, args.grid, args.reso)
+    dr.ctx.set_option("grid_mode", args.grid_mode)
+    dr.ctx.set_option("grid_group", args.grid_group)
     pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=dr.dev)
     gathered = torch.empty((world, 3), dtype=torch.float64, device=dr.dev) if world > 1 else None
     L = slam._abi.lib()
@@ -160,6 +164,8 @@ def main():
                  "finalize": args.grid * args.grid * 9}.get(dom, 0)
     kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "points": "k_scan_to_points", "compose": "k_pose_compose",
              "finalize": "k_grid_finalize"}.get(dom, dom)
+    if dom == "grid" and args.grid_mode == 1:
+        kname = "k_grid_update_win"
     traffic, tsrc = load_traffic(kname)
     achieved = alg_bytes / avg_s / 1e9
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -181,6 +187,7 @@ def main():
         "config": {"workload": "configs[1]: %d-scan replay (every %dth message of a 10 Hz stream), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid"
                                % (args.scans, args.stride, args.beams, args.max_iter, args.tol, args.grid, args.grid, args.reso),
                    "scans_per_step_per_gpu": scans_per_step, "point_buffers": args.points, "trajectories_per_gpu": 1,
+                   "grid_mode": args.grid_mode, "grid_group": args.grid_group,
                    "parallelism": "1 trajectory per GPU" + (", all_gather of final poses per step" if world > 1 else "")},
         "roofline": roofline,
     }

@@ -72,6 +72,10 @@ int slam_synchronize(slam_ctx *ctx);
 /* Synchronise and return-and-clear the sticky data error raised by kernels since the
  * last call (SLAM_OK, SLAM_ERR_NAN or SLAM_ERR_OVERFLOW). */
 int slam_check_status(slam_ctx *ctx);
+/* Tuning knobs (results never depend on them).  "grid_mode": 1 = ray casting through an
+ * LDS window per group of scans (default), 0 = direct global atomics.  "grid_group": scans
+ * per workgroup in window mode, 0 = automatic. */
+int slam_set_option(slam_ctx *ctx, const char *name, double value);
 /* Per-kernel-family timing with HIP events on the context's stream (bench.py roofline).
  * read: synchronises, adds up elapsed ms and launch counts since the last reset. */
 int slam_timing_enable(slam_ctx *ctx, int on);

@@ -430,3 +430,33 @@ def test_full_size_replay(slam, syn):
     assert np.array_equal(c1["pmap"] == 50, (c1["pass"] + c1["hit"]) == 0)
     assert it1.min() >= 2 and it1.max() <= 30
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 8, 11, 64])
+def test_grid_window_modes_are_bit_identical(slam, syn, group):
+    """The LDS-window ray caster (any group size, incl. windows smaller than the rays'
+    bounding box) and the direct-atomic one produce the same counters as the oracle."""
+    rep = syn.make_replay(40, 360, seed=2, stride=5, room_scale=2.0)      # 20 x 16 m room: rays leave a 192-cell window
+    ctx = slam.Context(0)
+    og = co.Grid(2000, 2000, 50.0, 20.0, 20.0)
+    oposes, _, _, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8, mt_grid=True)
+    for mode in (0, 1):
+        ctx.set_option("grid_mode", mode)
+        ctx.set_option("grid_group", group)
+        grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02, context=ctx)
+        poses, _, _ = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, context=ctx)
+        r = grid.read(0, want=("pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt), (mode, group)
+        assert grid.visits() == ov
+        grid.close()
+    # explicit-endpoint form (Mapping.update's arguments), many scans into one map
+    pts = [co.laser_to_points(r, AMIN, AMAX) for r in rep.ranges[1:]]
+    wp = [co.world_points(p, x, y) for p, (x, y) in zip(oposes, pts)]
+    ox, oy = np.stack([w[0] for w in wp]), np.stack([w[1] for w in wp])
+    ctx.set_option("grid_mode", 1)
+    grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02, context=ctx)
+    grid.update_host(ox, oy, oposes[:, 0], oposes[:, 1])
+    r = grid.read(0, want=("pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+    grid.close()
+    ctx.close()
