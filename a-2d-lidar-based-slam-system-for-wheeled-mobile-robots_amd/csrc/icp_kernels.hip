@@ -96,28 +96,87 @@ __device__ __forceinline__ Rigid2 kabsch_from_sums(double cax, double cay, doubl
 // ICP.findNearest (icp.py:90-114) for one query against the LDS-resident target cloud.
 // Strict '<' keeps the lowest index on ties (:103); NaN never wins.  Squared distances
 // are compared (sqrt is monotone); the distance itself is sqrt of the winner.
-__device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, int n_tar, double sx, double sy,
-                                          double &best_d2, int &best_j)
+//
+// Exact pruning.  The cloud is cut into blocks of kNNBlock consecutive points (beam order,
+// hence spatially compact) whose bounding boxes sit in LDS.  A candidate index `seed` (the
+// same beam index, or the previous iteration's match) gives an upper bound U on the
+// answer.  Blocks are visited in index order; a block is skipped when the box distance
+// lb exceeds min(U, best) in EVERY lane of the wave (the test is wave-uniform, so a
+// skipped block costs one box test instead of kNNBlock evaluations).  lb is evaluated with
+// the same operation sequence as a point distance (sub, mul, fma), and IEEE rounding is
+// monotone, so lb <= d2 holds for every point of the block as computed: a skipped block
+// holds only points strictly farther than the final minimum, evaluated blocks are scanned
+// in order with strict '<', and the result (index and distance) is bit-identical to the
+// exhaustive scan, ties included.  On the benchmark scans a wave evaluates ~20 % of the
+// blocks.
+constexpr int kNNBlock = 16;
+
+struct Box { double x0, x1, y0, y1; };
+
+__device__ __forceinline__ double dist2(double sx, double sy, double tx, double ty)
 {
+    double dx = sx - tx, dy = sy - ty;
+    return fma(dy, dy, dx * dx);
+}
+
+__device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, const Box *__restrict__ boxes, int nblocks,
+                                          int n_tar, double sx, double sy, int seed, bool active, double &best_d2, int &best_j)
+{
+    seed = min(max(seed, 0), n_tar - 1);
+    double2 ts = tarL[seed];
+    double U = dist2(sx, sy, ts.x, ts.y);
+    double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
+    if (!active) bound = -1.0;                   // padding lanes never ask for a block
     double best = INFINITY;
     int bj = 0;
-#pragma unroll 8
-    for (int j = 0; j < n_tar; ++j) {
-        double2 t = tarL[j];
-        double dx = sx - t.x, dy = sy - t.y;
-        double d2 = fma(dy, dy, dx * dx);
-        bool c = d2 < best;
-        best = c ? d2 : best;
-        bj = c ? j : bj;
+    for (int b = 0; b < nblocks; ++b) {
+        Box bx = boxes[b];
+        double dx = fmax(fmax(bx.x0 - sx, sx - bx.x1), 0.0);
+        double dy = fmax(fmax(bx.y0 - sy, sy - bx.y1), 0.0);
+        double lb = fma(dy, dy, dx * dx);
+        if (!__any(lb <= bound)) continue;       // wave-uniform
+        const double2 *t = tarL + b * kNNBlock;
+        const int j0 = b * kNNBlock;
+#pragma unroll
+        for (int k = 0; k < kNNBlock; ++k) {
+            double2 tk = t[k];
+            double d2 = dist2(sx, sy, tk.x, tk.y);
+            bool c = d2 < best;
+            best = c ? d2 : best;
+            bj = c ? j0 + k : bj;
+        }
+        bound = fmin(bound, best);
     }
     best_d2 = best;
     best_j = bj;
 }
 
-template <typename T>
-__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL)
+// LDS image of the target: float64 (x, y) pairs padded with NaN points to a whole number
+// of blocks (NaN never wins a comparison), then one bounding box per block.
+__host__ __device__ inline int nn_blocks(int n_tar) { return (n_tar + kNNBlock - 1) / kNNBlock; }
+__host__ __device__ inline size_t nn_lds_bytes(int n_tar)
 {
-    for (int j = threadIdx.x; j < n_tar; j += blockDim.x) tarL[j] = make_double2(ld(tar, j), ld(tar, (long)n_tar + j));
+    return (size_t)nn_blocks(n_tar) * (kNNBlock * sizeof(double2) + sizeof(Box));
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL, Box *boxes)
+{
+    const int nb = nn_blocks(n_tar), npad = nb * kNNBlock;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int j = threadIdx.x; j < npad; j += blockDim.x)
+        tarL[j] = j < n_tar ? make_double2(ld(tar, j), ld(tar, (long)n_tar + j)) : make_double2(qnan, qnan);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        Box bx{INFINITY, -INFINITY, INFINITY, -INFINITY};
+#pragma unroll
+        for (int k = 0; k < kNNBlock; ++k) {
+            double2 t = tarL[b * kNNBlock + k];
+            bx.x0 = fmin(bx.x0, t.x); bx.x1 = fmax(bx.x1, t.x);      // fmin / fmax ignore NaN
+            bx.y0 = fmin(bx.y0, t.y); bx.y1 = fmax(bx.y1, t.y);
+        }
+        boxes[b] = bx;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -127,8 +186,10 @@ template <typename T, int QPT>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2 *tarL = reinterpret_cast<double2 *>(smem);
-    double *red = reinterpret_cast<double *>(smem + (size_t)a.n_tar * sizeof(double2));  // [2][5][kMaxWaves]
+    const int nblocks = nn_blocks(a.n_tar);
+    double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNBlock]
+    Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNBlock * sizeof(double2));   // [nblocks]
+    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][5][kMaxWaves]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
@@ -137,9 +198,10 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     const T *src = static_cast<const T *>(a.src) + be * a.src_stride;
     const int n_src = a.n_src, n_tar = a.n_tar;
 
-    stage_target(tar, n_tar, tarL);
+    stage_target(tar, n_tar, tarL, boxes);
 
     double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
+    int seed[QPT];
     bool ok[QPT];
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
@@ -154,6 +216,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         }
         sx[q] = ax[q] = x;
         sy[q] = ay[q] = y;
+        seed[q] = i;                             // first guess: the same beam index
     }
     __syncthreads();
 
@@ -166,7 +229,8 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             double d2; int j;
-            nn_search(tarL, n_tar, sx[q], sy[q], d2, j);          // icp.py:67
+            nn_search(tarL, boxes, nblocks, n_tar, sx[q], sy[q], seed[q], ok[q], d2, j);   // icp.py:67
+            seed[q] = j;                                             // next iteration's guess
             double2 m = tarL[j];
             mx[q] = m.x; my[q] = m.y;
             double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
@@ -234,7 +298,7 @@ template <typename T>
 static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 {
     int qpt = (a.n_src + 1023) / 1024;
-    size_t lds = (size_t)a.n_tar * sizeof(double2) + 2 * 5 * kMaxWaves * sizeof(double);
+    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q)                                                                                        \
@@ -272,16 +336,18 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_nn(const T *src, const T *tar, int n_src, int n_tar, double *dist, int32_t *idx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblocks = nn_blocks(n_tar);
     double2 *tarL = reinterpret_cast<double2 *>(smem);
+    Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNBlock * sizeof(double2));
     const int b = blockIdx.y;
-    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL);
+    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL, boxes);
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = i < n_src;
     const T *s = src + (long)b * 2 * n_src;
     double sx = ok ? ld(s, i) : 0.0, sy = ok ? ld(s, (long)n_src + i) : 0.0;
     double d2; int j;
-    nn_search(tarL, n_tar, sx, sy, d2, j);
+    nn_search(tarL, boxes, nblocks, n_tar, sx, sy, i, ok, d2, j);
     if (ok) {
         dist[(long)b * n_src + i] = (d2 < INFINITY) ? sqrt(d2) : 0.0;
         idx[(long)b * n_src + i] = j;
@@ -292,7 +358,7 @@ template <typename T>
 static hipError_t launch_nn_t(const void *src, const void *tar, int B, int n_src, int n_tar, double *dist,
                               int32_t *idx, hipStream_t s)
 {
-    size_t lds = (size_t)n_tar * sizeof(double2);
+    size_t lds = nn_lds_bytes(n_tar);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nn<T>),

@@ -340,7 +340,7 @@ int slam_nn_dev(slam_ctx *c, const void *src, const void *tar, int B, int n_src,
     REQUIRE(src && tar && dist && idx, "null pointer");
     REQUIRE(B > 0 && n_src > 0 && n_tar > 0, "sizes must be positive");
     REQUIRE(dtype_size(dtype), "unknown dtype");
-    REQUIRE((size_t)n_tar * 16 <= 160 * 1024, "n_tar too large for the LDS-resident target (max 10240 points)");
+    REQUIRE(n_tar <= 8192, "n_tar too large for the LDS-resident target (max 8192 points)");
     Timed t(c, SLAM_K_NN);
     HIPCHK(launch_nn(src, tar, B, n_src, n_tar, dtype, dist, idx, c->stream));
     return SLAM_OK;
@@ -405,7 +405,7 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     REQUIRE(max_iter >= 0, "max_iter must be >= 0");
     REQUIRE(dtype_size(dtype), "unknown dtype");
     REQUIRE(n_src <= 8192, "n_src > 8192 not supported");
-    REQUIRE((size_t)n_tar * 16 + 2048 <= 160 * 1024, "n_tar too large for the LDS-resident target (max ~10000 points)");
+    REQUIRE(n_tar <= 8192, "n_tar too large for the LDS-resident target (max 8192 points)");
     IcpArgs a;
     a.tar = tar; a.src = src; a.prior = prior;
     a.tar_stride = tar_shared ? 0 : 2L * n_tar;
@@ -683,7 +683,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
     REQUIRE(max_iter >= 0, "max_iter must be >= 0");
     size_t ds = dtype_size(dtype);
     REQUIRE(ds, "unknown dtype");
-    REQUIRE(n <= 8192 && (size_t)n * 16 + 2048 <= 160 * 1024, "n too large");
+    REQUIRE(n <= 8192, "n too large (max 8192 beams)");
     const long pairs = (long)L * (n_scan - 1);
     REQUIRE(pairs < (1L << 31), "too many scan pairs for one launch");
     double *T = T_out;
