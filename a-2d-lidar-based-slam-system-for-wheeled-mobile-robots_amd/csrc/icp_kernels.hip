@@ -129,22 +129,26 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
     double best = INFINITY;
     int bj = 0;
+    Box nxt = boxes[0];
     for (int b = 0; b < nblocks; ++b) {
-        Box bx = boxes[b];
+        const Box bx = nxt;
+        nxt = boxes[b + 1];                      // boxes[] has at least one padding entry: prefetch under the scan
         double dx = fmax(fmax(bx.x0 - sx, sx - bx.x1), 0.0);
         double dy = fmax(fmax(bx.y0 - sy, sy - bx.y1), 0.0);
         double lb = fma(dy, dy, dx * dx);
         if (!__any(lb <= bound)) continue;       // wave-uniform
         const double2 *t = tarL + b * kNNBlock;
-        const int j0 = b * kNNBlock;
+        const double before = best;
+        int kk = 0;
 #pragma unroll
         for (int k = 0; k < kNNBlock; ++k) {
             double2 tk = t[k];
             double d2 = dist2(sx, sy, tk.x, tk.y);
             bool c = d2 < best;
-            best = c ? d2 : best;
-            bj = c ? j0 + k : bj;
+            best = fmin(best, d2);               // NaN never lowers it
+            kk = c ? k : kk;
         }
+        bj = (best < before) ? b * kNNBlock + kk : bj;
         bound = fmin(bound, best);
     }
     best_d2 = best;
@@ -154,9 +158,10 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // LDS image of the target: float64 (x, y) pairs padded with NaN points to a whole number
 // of blocks (NaN never wins a comparison), then one bounding box per block.
 __host__ __device__ inline int nn_blocks(int n_tar) { return (n_tar + kNNBlock - 1) / kNNBlock; }
+__host__ __device__ inline int nn_boxes_padded(int n_tar) { return nn_blocks(n_tar) + 1; }
 __host__ __device__ inline size_t nn_lds_bytes(int n_tar)
 {
-    return (size_t)nn_blocks(n_tar) * (kNNBlock * sizeof(double2) + sizeof(Box));
+    return (size_t)nn_blocks(n_tar) * kNNBlock * sizeof(double2) + (size_t)nn_boxes_padded(n_tar) * sizeof(Box);
 }
 
 template <typename T>
@@ -167,13 +172,15 @@ __device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *t
     for (int j = threadIdx.x; j < npad; j += blockDim.x)
         tarL[j] = j < n_tar ? make_double2(ld(tar, j), ld(tar, (long)n_tar + j)) : make_double2(qnan, qnan);
     __syncthreads();
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        Box bx{INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < nn_boxes_padded(n_tar); b += blockDim.x) {
+        Box bx{INFINITY, -INFINITY, INFINITY, -INFINITY};            // stays empty for the padding boxes
+        if (b < nb) {
 #pragma unroll
-        for (int k = 0; k < kNNBlock; ++k) {
-            double2 t = tarL[b * kNNBlock + k];
-            bx.x0 = fmin(bx.x0, t.x); bx.x1 = fmax(bx.x1, t.x);      // fmin / fmax ignore NaN
-            bx.y0 = fmin(bx.y0, t.y); bx.y1 = fmax(bx.y1, t.y);
+            for (int k = 0; k < kNNBlock; ++k) {
+                double2 t = tarL[b * kNNBlock + k];
+                bx.x0 = fmin(bx.x0, t.x); bx.x1 = fmax(bx.x1, t.x);  // fmin / fmax ignore NaN
+                bx.y0 = fmin(bx.y0, t.y); bx.y1 = fmax(bx.y1, t.y);
+            }
         }
         boxes[b] = bx;
     }
