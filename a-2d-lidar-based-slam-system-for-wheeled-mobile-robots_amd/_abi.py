@@ -18,7 +18,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "libslamhip.so")   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slam_hip.h")
 
 SLAM_OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NAN, ERR_OVERFLOW, ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6

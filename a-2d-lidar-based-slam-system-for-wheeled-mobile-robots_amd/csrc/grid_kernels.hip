@@ -358,6 +358,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
 
     // pass 2: walk the rays (the reference's float-error Bresenham, see cast_ray)
     unsigned nvis = 0;
+#ifdef SLAM_DIAG_NO_CAST
+    if (nrays < 0)
+#endif
     for (int r = tid; r < nrays; r += blockDim.x) {
         int s = r / n, i = r - s * n, pox, poy, b2 = 0;
         if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
@@ -386,6 +389,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     __syncthreads();
 
     // flush: one wave per window row, lanes along y (contiguous in the [x][y] map)
+#ifdef SLAM_DIAG_NO_FLUSH
+    if (W < 0)
+#endif
     for (int row = wave; row < W; row += nwaves) {
         size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
         for (int yy = lane; yy < H; yy += kWave) {

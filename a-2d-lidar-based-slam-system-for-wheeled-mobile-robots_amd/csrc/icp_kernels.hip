@@ -44,19 +44,42 @@ __device__ __forceinline__ void st(__half *p, long i, double v)
     p[i] = __float2half_rn(f);
 }
 
+// Wave-wide sum of a double, result in every lane, without touching LDS: four DPP
+// exchange steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror, row mirror;
+// addition is commutative, so both partners of an exchange hold the same bits), then the
+// four row sums are read with v_readlane and added in a fixed order.  Needs all 64 lanes
+// active.  Deterministic run to run and identical in all lanes.
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
+                            __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double x)
+{
+    x += dpp_xchg<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_xchg<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_xchg<0x141>(x);   // row_half_mirror
+    x += dpp_xchg<0x140>(x);   // row_mirror
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
 // Sum NV doubles over the workgroup; every thread receives the (bitwise identical)
-// totals.  Fixed butterfly + fixed wave order: deterministic run to run.  `scratch` must
-// alternate between two buffers on consecutive calls (no trailing barrier).
+// totals.  Fixed exchange pattern + fixed wave order: deterministic run to run.  `scratch`
+// ([NV][kMaxWaves]) must alternate between two buffers on consecutive calls (no trailing
+// barrier).
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int nwaves, int wave, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        v[k] = x;
-    }
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum_f64(v[k]);
     if (nwaves == 1) return;
     if (lane == 0) {
 #pragma unroll
@@ -109,7 +132,10 @@ __device__ __forceinline__ Rigid2 kabsch_from_sums(double cax, double cay, doubl
 // in order with strict '<', and the result (index and distance) is bit-identical to the
 // exhaustive scan, ties included.  On the benchmark scans a wave evaluates ~20 % of the
 // blocks.
-constexpr int kNNBlock = 16;
+#ifndef SLAM_NN_BLOCK
+#define SLAM_NN_BLOCK 16
+#endif
+constexpr int kNNBlock = SLAM_NN_BLOCK;
 
 struct Box { double x0, x1, y0, y1; };
 
@@ -127,6 +153,9 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
     double U = dist2(sx, sy, ts.x, ts.y);
     double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
+#ifdef SLAM_DIAG_NO_NN   /* timing-only build: results are wrong */
+    best_d2 = bound; best_j = seed; return;
+#endif
     double best = INFINITY;
     int bj = 0;
     Box nxt = boxes[0];
@@ -243,6 +272,9 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
             if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dist; }
         }
+        // Two passes, as the reference (centroids, then centred products, icp.py:154-160): when
+        // every source point matches the same target the centred products are exactly zero and
+        // R falls back to the identity, which one-pass raw moments would turn into rounding noise.
         block_sum<5>(v, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
         double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;   // icp.py:154-155
         double w[4] = {0, 0, 0, 0};
@@ -305,6 +337,10 @@ template <typename T>
 static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 {
     int qpt = (a.n_src + 1023) / 1024;
+    if (qpt < 2 && a.n_src > 128) qpt = 2;   // two queries per lane: fewer waves per pair, cheaper reductions (measured)
+#ifdef SLAM_ICP_MIN_QPT
+    if (qpt < SLAM_ICP_MIN_QPT && a.n_src > 64 * SLAM_ICP_MIN_QPT) qpt = SLAM_ICP_MIN_QPT;
+#endif
     size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
@@ -319,6 +355,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     }
     if (qpt <= 1) SLAM_ICP_CASE(1)
     else if (qpt <= 2) SLAM_ICP_CASE(2)
+    else if (qpt <= 3) SLAM_ICP_CASE(3)
     else if (qpt <= 4) SLAM_ICP_CASE(4)
     else if (qpt <= 8) SLAM_ICP_CASE(8)
     else return hipErrorInvalidValue;   // n_src > 8192
