@@ -220,17 +220,20 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
 // measured: profiles/r01_v1_*), far below what the walks themselves cost.  All rays of a
 // scan start in the same cell and consecutive scans of a stream overlap almost entirely,
 // so one workgroup takes a GROUP of consecutive scans of one stream, accumulates their
-// evidence in a window of the map held in LDS (up to 36,864 cells = 144 KiB of the CU's
-// 160 KiB; one packed uint32 per cell: pass count in bits 0-19, hit count in bits 20-31,
-// ds_add_u32), and flushes the non-zero cells once, row by row, so the global atomics
-// that remain are few and address-contiguous.  The window is the bounding box of the
-// group's ray origins and endpoints (clamped to the map) when that fits, else a
-// sub-rectangle of it around the first origin; cells of a ray outside the window fall
-// back to direct global atomics, so the result is exact for any window.
+// pass-through evidence in a window of the map held in LDS and flushes the non-zero cells
+// once, row by row, so the global atomics that remain are few and address-contiguous.
+// Window cells are 16-bit pass counters, two per dword, updated with ds_add_u32 of
+// 1 << 16*(cell & 1): a ray visits a cell at most once, so a count never exceeds the
+// group's ray count (<= 65,535 by construction) and never carries into its neighbour.
+// 36,864 cells = 72 KiB, so two workgroups share a CU's 160 KiB.  Hits (one per ray) go
+// straight to the global counters.  The window is the bounding box of the group's ray
+// origins and endpoints (clamped to the map) when that fits, else a sub-rectangle of it
+// around the first origin; cells of a ray outside the window fall back to direct global
+// atomics, so the result is exact for any window.
 // ---------------------------------------------------------------------------------
-constexpr int kWinCells = 36864;     // 144 KiB of LDS
+constexpr int kWinCells = 36864;     // 16-bit cells: 72 KiB of LDS
 constexpr int kWinMaxGroup = 64;     // scans per workgroup
-constexpr unsigned kHitShift = 20;   // needs group_size * n < 4096 hits and < 2^20 passes per cell
+constexpr int kRaysPerLane = 4;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
 
 struct ScanConst {
     double px, py, c, s;   // ray origin (world) and heading cos / sin (replay source only)
@@ -304,13 +307,65 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
+// Pass 2 of the window kernel: walk a workgroup's rays.  Rays are handed to waves 64 at a
+// time from an LDS counter (dynamic scheduling: ray lengths differ a lot, and with a static
+// assignment the workgroup waited for its slowest wave while its SIMDs idled).  The walk
+// itself is VALU-issue bound (measured: ~4 cycles per instruction per wave, insensitive to
+// occupancy, memory traffic and padding), so the body is kept short: the cell is kept as
+// (lx, ly) and advanced incrementally, and the path's last cell (the hit, mapping.py:45) is
+// remembered and written once after the loop.  It is the reference's loop
+// (bresenham.py:45-55) step for step.
+template <bool COVERS, class Src>
+__device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, const ScanConst *sc, int l, int s0, int n,
+                                              int nrays, int *next_ray, unsigned *win, int wx0, int wy0, int W, int H,
+                                              int Hp2, uint32_t *__restrict__ pass, uint32_t *__restrict__ hit)
+{
+    unsigned nvis = 0;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(next_ray, kWave);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= nrays) break;
+        const int r = base + lane;
+        if (r >= nrays) continue;
+        int s = r / n, i = r - s * n, pox, poy, b2 = 0;
+        Ray ry;
+        if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
+        if (!ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry)) continue;
+        const int klast = ry.flag ? 0 : ry.dx;                       // walk step of the path's LAST cell
+        const int ax_x = ry.steep ? 0 : 1, ax_y = ry.steep ? 1 : 0;  // cell step per walk step ...
+        const int ay_x = ry.steep ? ry.ystep : 0, ay_y = ry.steep ? 0 : ry.ystep;   // ... and per y step
+        int lx = ry.steep ? ry.y0 : ry.x0, ly = ry.steep ? ry.x0 : ry.y0;
+        int hx = -1, hy = -1;
+        double error = 0.0;                                           // bresenham.py:34
+        for (int k = 0; k <= ry.dx; ++k) {                            // :45
+            bool last = k == klast;
+            unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
+            bool inwin = wx < (unsigned)W && wy < (unsigned)H;
+            bool inmap = COVERS ? inwin : ((unsigned)lx < (unsigned)g.xw && (unsigned)ly < (unsigned)g.yw);   // mapping.py:41
+            nvis += inmap ? 1u : 0u;
+            hx = last ? lx : hx; hy = last ? ly : hy;
+            if (inwin && !last) atomicAdd(&win[wx * Hp2 + (wy >> 1)], 1u << ((wy & 1u) * 16u));          // mapping.py:43
+            if (!COVERS) { if (inmap && !inwin && !last) atomicAdd(&pass[(size_t)lx * g.yw + ly], 1u); }
+            error += ry.derr;                                         // bresenham.py:51
+            bool stepy = error >= 0.5;                                // :53
+            lx += ax_x + (stepy ? ay_x : 0);
+            ly += ax_y + (stepy ? ay_y : 0);
+            error = stepy ? error - 1.0 : error;                      // :55
+        }
+        if ((unsigned)hx < (unsigned)g.xw && (unsigned)hy < (unsigned)g.yw) atomicAdd(&hit[(size_t)hx * g.yw + hy], 1u);   // mapping.py:45
+    }
+    return nvis;
+}
+
 template <class Src>
 __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [kWinMaxGroup]
-    int *box = reinterpret_cast<int *>(smem + kWinMaxGroup * sizeof(ScanConst));          // bbox[4], window[4]
-    unsigned *win = reinterpret_cast<unsigned *>(smem + kWinMaxGroup * sizeof(ScanConst) + 64);
+    int *box = reinterpret_cast<int *>(smem + kWinMaxGroup * sizeof(ScanConst));          // bbox[4], window[4], flags
+    unsigned *win = reinterpret_cast<unsigned *>(smem + kWinMaxGroup * sizeof(ScanConst) + 64);   // [W][Hp/2] dwords
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
@@ -321,7 +376,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const int n = src.n, nrays = cnt * n;
 
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
-    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; }
+    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; }
     __syncthreads();
 
     // pass 1: bounding box of everything the group's rays can touch
@@ -340,65 +395,39 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     __syncthreads();
     if (tid == 0) {
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
-        int W = 0, H = 0;
+        int W = 0, H = 0, covers = 1;
         if (x0 <= x1 && y0 <= y1) {
             W = x1 - x0 + 1; H = y1 - y0 + 1;
-            if ((long)W * H > kWinCells) {                           // keep a sub-rectangle around the first origin
+            if ((long)W * ((H + 1) & ~1) > kWinCells) {               // keep a sub-rectangle around the first origin
                 int Hd = min(H, 192), Wd = min(W, kWinCells / Hd);
                 int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
+                covers = 0;
             }
         }
-        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H;
+        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers;
     }
     __syncthreads();
     const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
-    for (int w = tid; w < W * H; w += blockDim.x) win[w] = 0u;
+    const bool covers = box[8] != 0;      // the window holds every in-map cell the group can touch
+    const int Hp2 = (H + 1) >> 1;         // dwords per window row
+    for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
     __syncthreads();
 
-    // pass 2: walk the rays (the reference's float-error Bresenham, see cast_ray)
+    // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
     unsigned nvis = 0;
-#ifdef SLAM_DIAG_NO_CAST
-    if (nrays < 0)
-#endif
-    for (int r = tid; r < nrays; r += blockDim.x) {
-        int s = r / n, i = r - s * n, pox, poy, b2 = 0;
-        if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
-        Ray ry;
-        if (!ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry)) continue;
-        double error = 0.0;
-        int y = ry.y0;
-        for (int k = 0; k <= ry.dx; ++k) {
-            int x = ry.x0 + k;
-            int lx = ry.steep ? y : x, ly = ry.steep ? x : y;
-            bool last = ry.flag ? (k == 0) : (k == ry.dx);
-            if ((unsigned)lx < (unsigned)g.xw && (unsigned)ly < (unsigned)g.yw) {      // mapping.py:41
-                ++nvis;
-                unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
-                if (wx < (unsigned)W && wy < (unsigned)H) {
-                    atomicAdd(&win[wx * H + wy], last ? (1u << kHitShift) : 1u);
-                } else {
-                    size_t c = (size_t)lx * g.yw + ly;
-                    atomicAdd(last ? &hit[c] : &pass[c], 1u);
-                }
-            }
-            error += ry.derr;                                                        // bresenham.py:51
-            if (error >= 0.5) { y += ry.ystep; error -= 1.0; }                       // :53-55
-        }
-    }
+    if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], win, wx0, wy0, W, H, Hp2, pass, hit);
+    else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], win, wx0, wy0, W, H, Hp2, pass, hit);
     __syncthreads();
 
-    // flush: one wave per window row, lanes along y (contiguous in the [x][y] map)
-#ifdef SLAM_DIAG_NO_FLUSH
-    if (W < 0)
-#endif
+    // flush: one wave per window row, lanes along y (contiguous in the [x][y] map), two cells per lane
     for (int row = wave; row < W; row += nwaves) {
         size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
-        for (int yy = lane; yy < H; yy += kWave) {
-            unsigned v = win[row * H + yy];
-            unsigned p = v & ((1u << kHitShift) - 1u), h = v >> kHitShift;
-            if (p) atomicAdd(&pass[gbase + yy], p);
-            if (h) atomicAdd(&hit[gbase + yy], h);
+        for (int d = lane; d < Hp2; d += kWave) {
+            unsigned v = win[row * Hp2 + d];
+            unsigned p0 = v & 0xffffu, p1 = v >> 16;
+            if (p0) atomicAdd(&pass[gbase + 2 * d], p0);
+            if (p1) atomicAdd(&pass[gbase + 2 * d + 1], p1);          // p1 != 0 implies 2d+1 < H
         }
     }
     unsigned tot = wave_sum_u32(nvis);
@@ -415,7 +444,7 @@ template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
 {
-    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + (size_t)kWinCells * 4;
+    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + (size_t)kWinCells * 2;
     static bool attr_done[2] = {false, false};
     constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
     if (!attr_done[which]) {
@@ -426,19 +455,22 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     }
     int groups = (scans + group - 1) / group;
     long rays = (long)group * n;
-    int threads = rays >= 1024 ? 1024 : (int)(((rays + kWave - 1) / kWave) * kWave);
-    if (threads < 256) threads = 256;
+    long want = (rays + kRaysPerLane - 1) / kRaysPerLane;
+    int threads = want >= 1024 ? 1024 : (int)(((want + kWave - 1) / kWave) * kWave);
+    if (threads < 128) threads = 128;
     hipLaunchKernelGGL((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got);
     return hipGetLastError();
 }
 
-// group == 0: automatic (aim for >= 512 workgroups, at most 16 scans each).
+// group == 0: automatic.  Measured on the 1k-scan replay (profiles/r01_*): the kernel is
+// fastest with about one workgroup per two CUs (8 scans each); more, smaller groups re-flush
+// the same map region more often, fewer leave CUs idle.
 static int pick_group(int group, long total_scans, int scans_per_traj, int n)
 {
-    int gmax = std::min(kWinMaxGroup, 4095 / std::max(n, 1));
+    int gmax = std::min(kWinMaxGroup, 65535 / std::max(n, 1));
     if (gmax < 1) return 0;                                          // n too large for the packed counters
     if (group <= 0) {
-        long want = (total_scans + 511) / 512;
+        long want = (total_scans + 127) / 128;
         group = (int)std::min<long>(std::max<long>(want, 1), 16);
     }
     group = std::min(std::min(group, gmax), std::max(scans_per_traj, 1));

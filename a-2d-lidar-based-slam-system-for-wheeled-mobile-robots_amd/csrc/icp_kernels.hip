@@ -153,9 +153,6 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
     double U = dist2(sx, sy, ts.x, ts.y);
     double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
-#ifdef SLAM_DIAG_NO_NN   /* timing-only build: results are wrong */
-    best_d2 = bound; best_j = seed; return;
-#endif
     double best = INFINITY;
     int bj = 0;
     Box nxt = boxes[0];
@@ -338,9 +335,6 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 {
     int qpt = (a.n_src + 1023) / 1024;
     if (qpt < 2 && a.n_src > 128) qpt = 2;   // two queries per lane: fewer waves per pair, cheaper reductions (measured)
-#ifdef SLAM_ICP_MIN_QPT
-    if (qpt < SLAM_ICP_MIN_QPT && a.n_src > 64 * SLAM_ICP_MIN_QPT) qpt = SLAM_ICP_MIN_QPT;
-#endif
     size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
