@@ -503,50 +503,80 @@ hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const
 // walked by one lane, in the reference's evaluation order:
 //   x = (x + cos(th)*tx) - sin(th)*ty;  y = (y + sin(th)*tx) + cos(th)*ty;  th = th + dyaw.
 // ---------------------------------------------------------------------------------
-constexpr int kComposeChunk = 1024;
+constexpr int kComposeChunk = 2048;
+constexpr int kComposeThreads = 1024;
+constexpr int kComposeUnroll = 16;
 
-__global__ void __launch_bounds__(256) k_pose_compose(const double *__restrict__ T, const double *__restrict__ pose0, int n,
-                                                      double *__restrict__ poses)
+// The two serial scans are latency chains of float64 adds.  One lane walks the heading
+// chain and two lanes (x and y, same instruction stream) the position chains; operands are
+// read from LDS sixteen at a time, and the arrays are zero-padded to a multiple of 16 so the
+// unrolled bodies need no bounds checks (adding 0.0 leaves a running sum bit-identical).
+__global__ void __launch_bounds__(kComposeThreads) k_pose_compose(const double *__restrict__ T, const double *__restrict__ pose0, int n,
+                                                                  double *__restrict__ poses)
 {
     __shared__ double dyaw[kComposeChunk], thb[kComposeChunk];
-    __shared__ double pa[kComposeChunk], pb[kComposeChunk], pc[kComposeChunk], pd[kComposeChunk];
+    __shared__ double add1[2][kComposeChunk], sub2[2][kComposeChunk];   // [0]: x terms, [1]: y terms
     __shared__ double carry[3];
     const int l = blockIdx.x, tid = threadIdx.x;
     const double *Tl = T + 9 * (long)l * n;
     double *Pl = poses + 3 * (long)l * n;
     if (tid == 0) { carry[0] = pose0[3 * l]; carry[1] = pose0[3 * l + 1]; carry[2] = pose0[3 * l + 2]; }
     for (int base = 0; base < n; base += kComposeChunk) {
-        int cnt = min(kComposeChunk, n - base);
-        for (int k = tid; k < cnt; k += blockDim.x) {
-            const double *t = Tl + 9 * (long)(base + k);
-            dyaw[k] = atan2(t[3], t[0]);                             // icp.py:185
+        const int cnt = min(kComposeChunk, n - base);
+        const int cntp = (cnt + kComposeUnroll - 1) / kComposeUnroll * kComposeUnroll;
+        for (int k = tid; k < cntp; k += blockDim.x) {
+            double d = 0.0;
+            if (k < cnt) {
+                const double *t = Tl + 9 * (long)(base + k);
+                d = atan2(t[3], t[0]);                               // icp.py:185
+            }
+            dyaw[k] = d;
         }
         __syncthreads();
         if (tid == 0) {
             double th = carry[2];
-            for (int k = 0; k < cnt; ++k) { thb[k] = th; th = th + dyaw[k]; }   // :190
+            for (int k = 0; k < cntp; k += kComposeUnroll) {
+                double d[kComposeUnroll], o[kComposeUnroll];
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) d[u] = dyaw[k + u];
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) { o[u] = th; th = th + d[u]; }   // :190
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) thb[k + u] = o[u];
+            }
             carry[2] = th;
         }
         __syncthreads();
-        for (int k = tid; k < cnt; k += blockDim.x) {
-            const double *t = Tl + 9 * (long)(base + k);
-            double c = cos(thb[k]), s = sin(thb[k]);
-            pa[k] = c * t[2]; pb[k] = s * t[5]; pc[k] = s * t[2]; pd[k] = c * t[5];
+        for (int k = tid; k < cntp; k += blockDim.x) {
+            double a_ = 0, b_ = 0, c_ = 0, d_ = 0;
+            if (k < cnt) {
+                const double *t = Tl + 9 * (long)(base + k);
+                double c = cos(thb[k]), s = sin(thb[k]);
+                a_ = c * t[2]; b_ = s * t[5]; c_ = s * t[2]; d_ = c * t[5];
+            }
+            // x = (x + c*tx) - s*ty ;  y = (y + s*tx) + c*ty = (y + s*tx) - (-(c*ty))   (:188-189)
+            add1[0][k] = a_; sub2[0][k] = b_; add1[1][k] = c_; sub2[1][k] = -d_;
         }
         __syncthreads();
-        if (tid == 0) {
-            double x = carry[0], y = carry[1];
-            for (int k = 0; k < cnt; ++k) {
-                x = (x + pa[k]) - pb[k];                             // :188
-                y = (y + pc[k]) + pd[k];                             // :189
-                pa[k] = x; pc[k] = y;
+        if (tid < 2) {
+            const double *p = add1[tid], *q = sub2[tid];
+            double *o = add1[tid];
+            double v = carry[tid];
+            for (int k = 0; k < cntp; k += kComposeUnroll) {
+                double u1[kComposeUnroll], u2[kComposeUnroll];
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) { u1[u] = p[k + u]; u2[u] = q[k + u]; }
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) { v = (v + u1[u]) - u2[u]; u1[u] = v; }
+#pragma unroll
+                for (int u = 0; u < kComposeUnroll; ++u) o[k + u] = u1[u];
             }
-            carry[0] = x; carry[1] = y;
+            carry[tid] = v;
         }
         __syncthreads();
         for (int k = tid; k < cnt; k += blockDim.x) {
             double *p = Pl + 3 * (long)(base + k);
-            p[0] = pa[k]; p[1] = pc[k]; p[2] = thb[k] + dyaw[k];
+            p[0] = add1[0][k]; p[1] = add1[1][k]; p[2] = thb[k] + dyaw[k];
         }
         __syncthreads();
     }
@@ -554,7 +584,7 @@ __global__ void __launch_bounds__(256) k_pose_compose(const double *__restrict__
 
 hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pose_compose, dim3(L), dim3(256), 0, s, T, pose0, n, poses);
+    hipLaunchKernelGGL(k_pose_compose, dim3(L), dim3(kComposeThreads), 0, s, T, pose0, n, poses);
     return hipGetLastError();
 }
 
