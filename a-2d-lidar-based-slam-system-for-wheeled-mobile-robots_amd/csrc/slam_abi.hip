@@ -83,6 +83,7 @@ struct slam_ctx {
 struct slam_grid {
     GridDev d;
     unsigned long long *visits = nullptr;
+    size_t state_bytes = 0;        // pass[] + hit[] + visit counter, one allocation
     int8_t *pmap_one = nullptr;    // [xw][yw] read-back staging
     double *datamap_one = nullptr;
 };
@@ -502,9 +503,13 @@ int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double of
         g->d.pass_thresh = k;
     }
     g->d.status = c->status;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d.pass), cells * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->d.hit), cells * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->visits), 256);
+    // one allocation [pass | hit | visit counter] so that a reset is a single memset
+    g->state_bytes = align_up(cells * 4) * 2 + 256;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d.pass), g->state_bytes);
+    if (e == hipSuccess) {
+        g->d.hit = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(g->d.pass) + align_up(cells * 4));
+        g->visits = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(g->d.pass) + 2 * align_up(cells * 4));
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->pmap_one), align_up((size_t)xw * yw));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g->datamap_one), (size_t)xw * yw * 8);
     if (e != hipSuccess) {
@@ -523,9 +528,7 @@ int slam_grid_destroy(slam_ctx *c, slam_grid *g)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
-    if (g->d.pass) (void)hipFree(g->d.pass);
-    if (g->d.hit) (void)hipFree(g->d.hit);
-    if (g->visits) (void)hipFree(g->visits);
+    if (g->d.pass) (void)hipFree(g->d.pass);   // also holds hit[] and the visit counter
     if (g->pmap_one) (void)hipFree(g->pmap_one);
     if (g->datamap_one) (void)hipFree(g->datamap_one);
     delete g;
@@ -536,10 +539,7 @@ int slam_grid_reset(slam_ctx *c, slam_grid *g)
 {
     TRY(use(c));
     REQUIRE(g, "null grid");
-    size_t cells = (size_t)g->d.G * g->d.xw * g->d.yw;
-    HIPCHK(hipMemsetAsync(g->d.pass, 0, cells * 4, c->stream));
-    HIPCHK(hipMemsetAsync(g->d.hit, 0, cells * 4, c->stream));
-    HIPCHK(hipMemsetAsync(g->visits, 0, 256, c->stream));
+    HIPCHK(hipMemsetAsync(g->d.pass, 0, g->state_bytes, c->stream));
     return SLAM_OK;
 }
 
