@@ -233,6 +233,8 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
 // ---------------------------------------------------------------------------------
 constexpr int kWinCells = 36864;     // 16-bit cells: 72 KiB of LDS
 constexpr int kWinMaxGroup = 64;     // scans per workgroup
+constexpr int kSortBins = 128;        // ray-length histogram (4 cells per bin)
+constexpr int kMaxSortRays = 8192;    // rays per workgroup that can be length-sorted (u16 ids in LDS)
 constexpr int kRaysPerLane = 4;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
 
 struct ScanConst {
@@ -308,8 +310,8 @@ __device__ __forceinline__ int wave_max_i32(int v)
 }
 
 // Pass 2 of the window kernel: walk a workgroup's rays.  Rays are handed to waves 64 at a
-// time from an LDS counter (dynamic scheduling: ray lengths differ a lot, and with a static
-// assignment the workgroup waited for its slowest wave while its SIMDs idled).  The walk
+// time from an LDS counter, in order of decreasing length when the group was sorted in pass 1
+// (a wave runs as long as its longest ray: unsorted, 54 % of the lane-steps were idle).  The walk
 // itself is VALU-issue bound (measured: ~4 cycles per instruction per wave, insensitive to
 // occupancy, memory traffic and padding), so the body is kept short: the cell is kept as
 // (lx, ly) and advanced incrementally, and the path's last cell (the hit, mapping.py:45) is
@@ -317,8 +319,9 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // (bresenham.py:45-55) step for step.
 template <bool COVERS, class Src>
 __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, const ScanConst *sc, int l, int s0, int n,
-                                              int nrays, int *next_ray, unsigned *win, int wx0, int wy0, int W, int H,
-                                              int Hp2, uint32_t *__restrict__ pass, uint32_t *__restrict__ hit)
+                                              int nrays, int *next_ray, const unsigned short *order, unsigned *win, int wx0,
+                                              int wy0, int W, int H, int Hp2, uint32_t *__restrict__ pass,
+                                              uint32_t *__restrict__ hit)
 {
     unsigned nvis = 0;
     const int lane = threadIdx.x & 63;
@@ -327,8 +330,8 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
         if (lane == 0) base = atomicAdd(next_ray, kWave);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= nrays) break;
-        const int r = base + lane;
-        if (r >= nrays) continue;
+        if (base + lane >= nrays) continue;
+        const int r = order ? (int)order[base + lane] : base + lane;   // longest rays first when sorted
         int s = r / n, i = r - s * n, pox, poy, b2 = 0;
         Ray ry;
         if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
@@ -365,7 +368,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [kWinMaxGroup]
     int *box = reinterpret_cast<int *>(smem + kWinMaxGroup * sizeof(ScanConst));          // bbox[4], window[4], flags
-    unsigned *win = reinterpret_cast<unsigned *>(smem + kWinMaxGroup * sizeof(ScanConst) + 64);   // [W][Hp/2] dwords
+    int *hist = box + 16;                                                                 // [kSortBins]
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [kMaxSortRays]
+    unsigned *win = reinterpret_cast<unsigned *>(order + kMaxSortRays);                   // [W][Hp/2] dwords
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
@@ -377,15 +382,24 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
 
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
     if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; }
+    const bool sorted = nrays <= kMaxSortRays;
+    unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
+    if (tid < kSortBins) hist[tid] = 0;
     __syncthreads();
 
     // pass 1: bounding box of everything the group's rays can touch
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
     for (int r = tid; r < nrays; r += blockDim.x) {
-        int s = r / n, i = r - s * n, pox, poy;
+        int s = r / n, i = r - s * n, pox, poy, len = 0;
         if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, bad)) {
             bx0 = min(bx0, min(pox, sc[s].pcx)); bx1 = max(bx1, max(pox, sc[s].pcx));
             by0 = min(by0, min(poy, sc[s].pcy)); by1 = max(by1, max(poy, sc[s].pcy));
+            len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
+        }
+        if (sorted) {                                                // bin by length, longest first
+            int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);
+            bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
+            atomicAdd(&hist[bin], 1);
         }
     }
     bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
@@ -411,17 +425,37 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
     const bool covers = box[8] != 0;      // the window holds every in-map cell the group can touch
     const int Hp2 = (H + 1) >> 1;         // dwords per window row
+    if (sorted) {
+        // counting sort of the ray ids by length bin: exclusive scan of the histogram (wave 0),
+        // then every ray claims a slot in its bin.  Order inside a bin is arbitrary; the map
+        // update does not depend on ray order.
+        if (wave == 0) {
+            int a = hist[2 * lane], b2 = hist[2 * lane + 1], tot = a + b2, inc = tot;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) { int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
+            hist[2 * lane] = inc - tot;
+            hist[2 * lane + 1] = inc - tot + a;
+        }
+        __syncthreads();
+        for (int r = tid; r < nrays; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
+        __syncthreads();
+    }
     for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
     __syncthreads();
 
     // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
     unsigned nvis = 0;
-    if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], win, wx0, wy0, W, H, Hp2, pass, hit);
-    else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], win, wx0, wy0, W, H, Hp2, pass, hit);
+    const unsigned short *ord = sorted ? order : nullptr;
+    if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
+    else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
     __syncthreads();
 
     // flush: one wave per window row, lanes along y (contiguous in the [x][y] map), two cells per lane
-    for (int row = wave; row < W; row += nwaves) {
+    // every workgroup flushes the same part of the map: start each one at a different row so
+    // that concurrent flushes do not queue on the same addresses
+    const int rot = W > 0 ? (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)W) : 0;
+    for (int rr = wave; rr < W; rr += nwaves) {
+        const int row = rr + rot < W ? rr + rot : rr + rot - W;
         size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
         for (int d = lane; d < Hp2; d += kWave) {
             unsigned v = win[row * Hp2 + d];
@@ -444,7 +478,7 @@ template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
 {
-    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + (size_t)kWinCells * 2;
+    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + kSortBins * 4 + kMaxSortRays * 2 + (size_t)kWinCells * 2;
     static bool attr_done[2] = {false, false};
     constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
     if (!attr_done[which]) {
