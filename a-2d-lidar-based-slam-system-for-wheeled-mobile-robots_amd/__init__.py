@@ -18,10 +18,10 @@ from ._abi import Context, LibraryMissing, SlamError, default_context
 from .bresenham import bresenham, rasterize
 from .icp import ICP, scan_to_pc
 from .mapping import Mapping
-from .replay import DeviceGrid, DeviceReplay, icp_batch_host, replay_host
+from .replay import DeviceGrid, DeviceReplay, icp_batch_host, particles_host, prior_matrices, replay_host
 from .slam_ekf import SLAM_EKF
 from .synthetic import LaserScan
 
 __all__ = ["ICP", "Mapping", "bresenham", "rasterize", "SLAM_EKF", "LaserScan", "Context", "default_context",
-           "DeviceGrid", "DeviceReplay", "replay_host", "icp_batch_host", "scan_to_pc", "SlamError",
+           "DeviceGrid", "DeviceReplay", "replay_host", "icp_batch_host", "particles_host", "prior_matrices", "scan_to_pc", "SlamError",
            "LibraryMissing", "param", "synthetic"]

@@ -71,6 +71,8 @@ _SIGS = {
     "slam_grid_visits": ([_vp, _vp, C.POINTER(C.c_uint64)], _i),
     "slam_bresenham_batch": ([_vp, _vp, _vp, _i, _vp, _vp, _vp, C.c_int64], _i),
     "slam_replay": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "slam_particles": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp], _i),
+    "slam_particles_dev": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp], _i),
     "slam_replay_dev": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
 }
 

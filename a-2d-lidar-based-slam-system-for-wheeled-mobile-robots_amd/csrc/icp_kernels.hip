@@ -582,8 +582,39 @@ __global__ void __launch_bounds__(kComposeThreads) k_pose_compose(const double *
     }
 }
 
-hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s)
+// One dead-reckoning step per hypothesis (n = 1, many trajectories): pose = pose0 (+) M with
+// M = T.[prior; 0 0 1] when a prior was applied to the source before the solve (the solve's T
+// maps the PERTURBED source, so the motion of the original scan is the product).
+__global__ void __launch_bounds__(256) k_pose_step(const double *__restrict__ T, const double *__restrict__ pose0,
+                                                   const double *__restrict__ prior, int L, double *__restrict__ poses)
 {
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double *t = T + 9 * (long)l;
+    double m00 = t[0], m10 = t[3], m02 = t[2], m12 = t[5];
+    if (prior) {
+        const double *p = prior + 6 * (long)l;
+        m00 = t[0] * p[0] + t[1] * p[3];
+        m10 = t[3] * p[0] + t[4] * p[3];
+        m02 = t[0] * p[2] + t[1] * p[5] + t[2];
+        m12 = t[3] * p[2] + t[4] * p[5] + t[5];
+    }
+    double x = pose0[3 * l], y = pose0[3 * l + 1], th = pose0[3 * l + 2];
+    double dyaw = atan2(m10, m00);                                   // icp.py:185
+    double c = cos(th), s = sin(th);
+    poses[3 * l] = (x + c * m02) - s * m12;                          // :188
+    poses[3 * l + 1] = (y + s * m02) + c * m12;                      // :189
+    poses[3 * l + 2] = th + dyaw;                                    // :190
+}
+
+hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
+                               const double *prior)
+{
+    if (prior || (n == 1 && L > 64)) {
+        if (n != 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_pose_compose, dim3(L), dim3(kComposeThreads), 0, s, T, pose0, n, poses);
     return hipGetLastError();
 }

@@ -756,4 +756,77 @@ int slam_replay(slam_ctx *c, const float *ranges, const double *cos_t, const dou
     return check_status_sync(c);
 }
 
+/* ---- particle hypotheses ----------------------------------------------------------- */
+
+int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
+                       const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
+                       void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges2 && cos_t && sin_t && pose_prev && pts_ws && poses_out && T_out, "null pointer");
+    REQUIRE(P > 0 && n > 0 && n <= 8192, "need P > 0 and 0 < n <= 8192");
+    REQUIRE(max_iter >= 0, "max_iter must be >= 0");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    REQUIRE(!grid || grid->d.G >= P, "the grid object needs one map per particle");
+    REQUIRE(!grid || P <= 65535, "at most 65535 particles per call when ray casting");
+    {
+        Timed t(c, SLAM_K_POINTS);
+        HIPCHK(launch_scan_to_points(ranges2, cos_t, sin_t, 2L * n, n, 1, dtype, pts_ws, c->stream));
+    }
+    {
+        IcpArgs a;
+        a.tar = pts_ws;
+        a.src = static_cast<const char *>(pts_ws) + 2 * (size_t)n * ds;
+        a.prior = prior;
+        a.tar_stride = a.src_stride = 0;   // every hypothesis matches the same scan pair
+        a.ppt = 0;
+        a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
+        a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
+        Timed t(c, SLAM_K_ICP);
+        HIPCHK(launch_icp(a, dtype, c->stream));
+    }
+    {
+        Timed t(c, SLAM_K_COMPOSE);
+        HIPCHK(launch_pose_compose(T_out, pose_prev, P, 1, poses_out, c->stream, prior));
+    }
+    if (grid) {
+        Timed t(c, SLAM_K_GRID);
+        HIPCHK(launch_grid_update_replay_win(grid->d, ranges2, cos_t, sin_t, poses_out, P, 2, n, nullptr, 1, c->stream,
+                                             /*shared_scans=*/1, /*grid_per_traj=*/1));
+    }
+    return SLAM_OK;
+}
+
+int slam_particles(slam_ctx *c, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
+                   const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
+                   double *poses_out, double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges2 && cos_t && sin_t && pose_prev && poses_out, "null pointer");
+    REQUIRE(P > 0 && n > 0, "sizes must be positive");
+    size_t ds = dtype_size(dtype);
+    REQUIRE(ds, "unknown dtype");
+    TRY(arena_reserve(c, c->staging, align_up((size_t)2 * n * 4) + 2 * align_up((size_t)n * 8) + align_up((size_t)P * 48) +
+                                         align_up((size_t)P * 24) * 2 + align_up(4 * (size_t)n * ds) + align_up((size_t)P * 72) +
+                                         align_up((size_t)P * 4) + 4096));
+    float *d_r = carve<float>(c->staging, 2 * (size_t)n);
+    double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
+    double *d_pr = prior ? carve<double>(c->staging, (size_t)P * 6) : nullptr;
+    double *d_p0 = carve<double>(c->staging, (size_t)P * 3), *d_P = carve<double>(c->staging, (size_t)P * 3);
+    char *d_pts = carve<char>(c->staging, 4 * (size_t)n * ds);
+    double *d_T = carve<double>(c->staging, (size_t)P * 9);
+    int32_t *d_it = carve<int32_t>(c->staging, P);
+    H2D(d_r, ranges2, 2 * (size_t)n * 4);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_s, sin_t, (size_t)n * 8);
+    if (prior) H2D(d_pr, prior, (size_t)P * 48);
+    H2D(d_p0, pose_prev, (size_t)P * 24);
+    TRY(slam_particles_dev(c, d_r, d_c, d_s, n, dtype, d_pr, d_p0, P, max_iter, tol, grid, d_pts, d_P, d_T, d_it));
+    D2H(poses_out, d_P, (size_t)P * 24);
+    if (T_out) D2H(T_out, d_T, (size_t)P * 72);
+    if (iters_out) D2H(iters_out, d_it, (size_t)P * 4);
+    return check_status_sync(c);
+}
+
 }  // extern "C"

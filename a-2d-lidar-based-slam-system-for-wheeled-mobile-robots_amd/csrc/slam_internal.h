@@ -34,7 +34,9 @@ hipError_t launch_nn(const void *src, const void *tar, int B, int n_src, int n_t
 hipError_t launch_kabsch(const double *src, const double *tar, int B, int n, double *T_out, hipStream_t s);
 hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const double *sin_t, long total,
                                  int n, int clip_inf, int dtype, void *pts, hipStream_t s);
-hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s);
+// prior: nullable [L][6] (n must be 1): the step composed is T.[prior; 0 0 1] (particle hypotheses).
+hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
+                               const double *prior = nullptr);
 
 // ---- grid --------------------------------------------------------------------------
 struct GridDev {
@@ -61,7 +63,8 @@ hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const doub
                                   const double *cy, int B, int n, int group, hipStream_t s);
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t,
                                          const double *sin_t, const double *poses, int L, int n_scan, int n,
-                                         const int32_t *grid_of_traj, int group, hipStream_t s);
+                                         const int32_t *grid_of_traj, int group, hipStream_t s, int shared_scans = 0,
+                                         int grid_per_traj = 0);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
 hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);

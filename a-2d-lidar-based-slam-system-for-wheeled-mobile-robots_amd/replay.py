@@ -65,6 +65,38 @@ def icp_batch_host(tar, src, max_iter=30, tolerance=0.001, dtype="f64", prior=No
     return T.reshape(B, 3, 3), it, err
 
 
+def prior_matrices(priors):
+    """(dx, dy, dtheta) perturbations [P,3] -> 2x3 matrices [P,2,3] (rotation by dtheta,
+    then translation), the form ``slam_icp_batch`` / ``slam_particles`` take."""
+    pr = np.asarray(priors, dtype=np.float64).reshape(-1, 3)
+    m = np.zeros((pr.shape[0], 2, 3))
+    m[:, 0, 0], m[:, 0, 1], m[:, 0, 2] = np.cos(pr[:, 2]), -np.sin(pr[:, 2]), pr[:, 0]
+    m[:, 1, 0], m[:, 1, 1], m[:, 1, 2] = np.sin(pr[:, 2]), np.cos(pr[:, 2]), pr[:, 1]
+    return m
+
+
+def particles_host(ranges_prev, ranges_cur, angle_min, angle_max, prior_mats, pose_prev, grid=None, max_iter=30,
+                   tolerance=0.001, dtype="f64", context=None):
+    """P pose hypotheses of one scan pair (``slam_particles``, BASELINE.json configs[2]):
+    per hypothesis an ICP solve on the prior-perturbed source, one dead-reckoning step from
+    ``pose_prev[p]`` and a ray cast of the current scan into map p of ``grid`` (a
+    :class:`DeviceGrid` with G >= P maps, or None).  Returns (poses [P,3], T [P,3,3], iters [P])."""
+    ctx = context or _abi.default_context()
+    r2 = np.ascontiguousarray(np.stack([np.asarray(ranges_prev, dtype=np.float32), np.asarray(ranges_cur, dtype=np.float32)]))
+    n = r2.shape[1]
+    ct, st = _abi.trig_tables(angle_min, angle_max, n)
+    pm = None if prior_mats is None else np.ascontiguousarray(np.asarray(prior_mats, dtype=np.float64).reshape(-1, 6))
+    pp = np.ascontiguousarray(np.asarray(pose_prev, dtype=np.float64).reshape(-1, 3))
+    P = pp.shape[0]
+    if pm is not None and pm.shape[0] != P:
+        raise ValueError("prior_mats and pose_prev disagree on the number of hypotheses")
+    poses, T, it = np.empty((P, 3)), np.empty((P, 9)), np.empty(P, dtype=np.int32)
+    _abi.check(_abi.lib().slam_particles(ctx.handle, _abi.ptr(r2), _abi.ptr(ct), _abi.ptr(st), n, _abi.DTYPES[dtype],
+                                         _abi.ptr(pm), _abi.ptr(pp), P, int(max_iter), float(tolerance),
+                                         grid._h if grid is not None else None, _abi.ptr(poses), _abi.ptr(T), _abi.ptr(it)))
+    return poses, T.reshape(P, 3, 3), it
+
+
 class DeviceGrid:
     """G occupancy maps resident on the device (``slam_grid_*``)."""
 

@@ -181,6 +181,24 @@ int slam_replay_dev(slam_ctx *ctx, const float *ranges, const double *cos_t, con
                     slam_grid *grid, const int32_t *grid_of_traj, void *pts_ws, double *poses_out,
                     double *T_out, int32_t *iters_out);
 
+/* ---- particle hypotheses (BASELINE.json configs[2]) --------------------------------- */
+/* The same two operators batched over P pose hypotheses of ONE scan pair (the reference
+ * has no particle filter; this is ICP.process + Mapping.update evaluated P times with
+ * perturbed priors).  ranges2 [2][n] float32: previous scan (target) then current scan
+ * (source).  prior [P][6] (nullable): 2x3 matrix applied to the source points before the
+ * solve; the hypothesis' motion is then M = T.[prior; 0 0 1].  pose_prev [P][3].
+ * Per hypothesis p: T_p = ICP.process(tar, prior_p . src) (W12m/icp.py:38-88);
+ * pose_p = pose_prev_p (+) M_p (icp.py:185-190); the current scan is ray-cast from pose_p
+ * into map p of `grid` (needs G >= P maps; W12m/mapping.py:22-51).
+ * poses_out [P][3]; T_out [P][9]; iters_out [P] (host form: T_out / iters_out nullable). */
+int slam_particles(slam_ctx *ctx, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
+                   const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
+                   double *poses_out, double *T_out, int32_t *iters_out);
+/* Device form: pts_ws holds 4*n elements of `dtype`; T_out is required. */
+int slam_particles_dev(slam_ctx *ctx, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
+                       const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
+                       void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out);
+
 #ifdef __cplusplus
 }
 #endif

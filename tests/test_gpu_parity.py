@@ -460,3 +460,32 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
     grid.close()
     ctx.close()
+
+
+def test_particle_hypotheses_pipeline_vs_oracle(slam, syn):
+    """BASELINE configs[2] operator: P perturbed priors of one scan pair, one map per
+    hypothesis.  Oracle = loop over hypotheses (ICP on the perturbed source, one
+    dead-reckoning step with M = T.prior, ray cast of the original scan)."""
+    rep = syn.make_replay(2, 360, seed=2, stride=5)
+    P = 24
+    mats = slam.prior_matrices(syn.particle_priors(P, seed=2))
+    pose_prev = np.random.default_rng(4).normal(0, 0.5, size=(P, 3))
+    grid = slam.DeviceGrid.metric(P, 400, 400, 0.05)
+    poses, T, it = slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, mats, pose_prev, grid=grid)
+    tar = np.array(co.laser_to_points(rep.ranges[0], AMIN, AMAX))
+    src = np.array(co.laser_to_points(rep.ranges[1], AMIN, AMAX))
+    for p in range(P):
+        m = mats[p]
+        sp = np.stack([m[0, 0] * src[0] + m[0, 1] * src[1] + m[0, 2], m[1, 0] * src[0] + m[1, 1] * src[1] + m[1, 2]])
+        oT, oit, _ = co.icp_process(tar, sp, 30, 0.001)
+        M = np.eye(3)
+        M[0, 0] = oT[0, 0] * m[0, 0] + oT[0, 1] * m[1, 0]; M[1, 0] = oT[1, 0] * m[0, 0] + oT[1, 1] * m[1, 0]
+        M[0, 2] = oT[0, 0] * m[0, 2] + oT[0, 1] * m[1, 2] + oT[0, 2]; M[1, 2] = oT[1, 0] * m[0, 2] + oT[1, 1] * m[1, 2] + oT[1, 2]
+        op = co.compose_pose(pose_prev[p], M)
+        assert it[p] == oit and np.max(np.abs(T[p] - oT)) < FTOL and np.max(np.abs(poses[p] - op)) < FTOL, p
+        og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+        ox, oy = co.world_points(op, src[0], src[1])
+        og.update(ox, oy, op[0], op[1])
+        r = grid.read(p, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), p
+    assert len(set(it.tolist())) > 1

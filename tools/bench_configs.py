@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configurations that are not the bench.py
+headline (configs[2] particles, configs[4] dense scan, long replays).  Prints one JSON line
+per configuration.  Not part of the driver contract; results are kept under profiles/."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+AMIN, AMAX = -3.14159, 3.14159
+
+
+def timed(fn, steps, warmup, torch):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def particles(slam, torch, P, steps, warmup):
+    """configs[2]: one 360-beam scan pair, P perturbed priors, one 400x400 @ 0.05 m map per
+    particle (maps persist across steps, as in a particle filter: no reset in the step)."""
+    A = slam._abi
+    dev = torch.device("cuda", 0)
+    ctx = A.Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    rep = slam.synthetic.make_replay(2, 360, seed=2, stride=5)
+    n = 360
+    ct, st = A.trig_tables(AMIN, AMAX, n)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ranges2, cos_t, sin_t = d(rep.ranges.astype(np.float32)), d(ct), d(st)
+    prior = d(slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2)).reshape(P, 6))
+    pose_prev = d(np.zeros((P, 3)))
+    pts = torch.empty(4 * n, dtype=torch.float64, device=dev)
+    poses = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    T = torch.empty((P, 9), dtype=torch.float64, device=dev)
+    iters = torch.empty(P, dtype=torch.int32, device=dev)
+    grid = slam.DeviceGrid.metric(P, 400, 400, 0.05, context=ctx)
+    pmap = torch.empty((P, 400, 400), dtype=torch.int8, device=dev)
+    L = A.lib()
+
+    def step():
+        A.check(L.slam_particles_dev(ctx.handle, ranges2.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), n, A.F64,
+                                     prior.data_ptr(), pose_prev.data_ptr(), P, 30, 1e-3, grid._h, pts.data_ptr(),
+                                     poses.data_ptr(), T.data_ptr(), iters.data_ptr()))
+        A.check(L.slam_grid_finalize_dev(ctx.handle, grid._h, pmap.data_ptr()))
+
+    ctx.timing_enable(True)
+    dt = timed(step, steps, warmup, torch)
+    fam = ctx.timing_read()
+    ctx.check_status()
+    visits = grid.visits() / (steps + warmup)
+    return {"config": "configs[2]: %d particle hypotheses of one 360-beam scan pair, 400x400@0.05m map per particle" % P,
+            "value": P / dt, "unit": "particle-scans/s", "ms_per_step": dt * 1e3, "mean_iters": float(iters.float().mean()),
+            "cell_visits_per_step": visits,
+            "kernel_ms_per_step": {k: v[0] / v[1] for k, v in fam.items() if v[1]},
+            "finalize_GBps": P * 160000 * 9 / (fam["finalize"][0] / fam["finalize"][1] * 1e-3) / 1e9,
+            "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
+
+
+def replay(slam, torch, scans, beams, grid_n, reso, room, points, steps, warmup, label):
+    rep = slam.synthetic.make_replay(scans, beams, seed=3 if beams == 1080 else 1, room_scale=room, stride=5)
+    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype=points)
+    grid = dr.make_grid(1, grid_n, grid_n, reso)
+    pmap = torch.empty((grid_n, grid_n), dtype=torch.int8, device=dr.dev)
+    A = slam._abi
+
+    def step():
+        dr.run(reset_grid=True)
+        A.check(A.lib().slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
+
+    dr.ctx.timing_enable(True)
+    dt = timed(step, steps, warmup, torch)
+    fam = dr.ctx.timing_read()
+    _, _, iters = dr.results()
+    visits = grid.visits()
+    return {"config": label, "value": dr.scans_per_run / dt, "unit": "scans/s", "ms_per_step": dt * 1e3,
+            "mean_iters": float(iters.mean()), "cell_visits_per_step": visits,
+            "kernel_ms_per_step": {k: v[0] / v[1] for k, v in fam.items() if v[1]},
+            "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="particles,dense,long")
+    ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    import torch
+    slam = importlib.import_module("a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd")
+    for w in args.which.split(","):
+        if w == "particles":
+            out = particles(slam, torch, args.particles, args.steps, args.warmup)
+        elif w == "dense":
+            out = replay(slam, torch, 1000, 1080, 2000, 0.02, 2.0, "f16", args.steps, args.warmup,
+                         "configs[4]: 1k-scan replay, 1080 beams, 2000x2000@0.02m grid, f16 point buffers, room x2")
+        elif w == "long":
+            out = replay(slam, torch, 5000, 360, 400, 0.05, 1.0, "f64", args.steps, args.warmup,
+                         "configs[3] per-GPU share: 5k-scan replay, 360 beams, 400x400@0.05m grid")
+        else:
+            continue
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
