@@ -247,7 +247,10 @@ struct ReplaySource {
     const float *ranges;
     const double *cos_t, *sin_t, *poses;
     int n_scan, n;
+    long traj_stride;      // floats between trajectories' scan blocks (0: every trajectory reads the same scans)
+    int grid_per_traj;     // trajectory l casts into map l (particle hypotheses, BASELINE configs[2])
     __device__ int scans_per_traj() const { return n_scan - 1; }
+    __device__ int own_grid(int l) const { return grid_per_traj ? l : 0; }
     __device__ void scan_const(int l, int k, const GridDev &g, ScanConst &sc) const
     {
         const double *pose = poses + 3 * ((size_t)l * (n_scan - 1) + k);
@@ -260,7 +263,7 @@ struct ReplaySource {
     // false: beam skipped (mapping.py:30) or flagged in `bad`
     __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
     {
-        double rr = (double)ranges[((size_t)l * n_scan + k + 1) * n + i];
+        double rr = (double)ranges[(size_t)l * traj_stride + (size_t)(k + 1) * n + i];
         if (rr == INFINITY) rr = 30.0;                               // slam_ekf.py:119
         double lx = cos_t[i] * rr, ly = sin_t[i] * rr;               // :122
         double x = sc.c * lx + (-sc.s) * ly + sc.px * 1.0;           // u2T(pose).dot(pc), :89
@@ -278,6 +281,7 @@ struct ExplicitSource {
     const double *ox, *oy, *cx, *cy;
     int B, n;
     __device__ int scans_per_traj() const { return B; }
+    __device__ int own_grid(int) const { return 0; }
     __device__ void scan_const(int, int k, const GridDev &g, ScanConst &sc) const
     {
         sc.px = cx[k]; sc.py = cy[k]; sc.c = 1.0; sc.s = 0.0;
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const int l = blockIdx.y;
     const int s0 = blockIdx.x * group_size;
     const int cnt = min(group_size, src.scans_per_traj() - s0);
-    const int gi = got ? got[l] : 0;
+    const int gi = got ? got[l] : src.own_grid(l);
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
     const int n = src.n, nrays = cnt * n;
 
@@ -522,12 +526,15 @@ hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const doub
 
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                          const double *poses, int L, int n_scan, int n, const int32_t *got, int group,
-                                         hipStream_t s)
+                                         hipStream_t s, int shared_scans, int grid_per_traj)
 {
     if (n_scan < 2) return hipSuccess;
     int G = pick_group(group, (long)L * (n_scan - 1), n_scan - 1, n);
-    if (G == 0) return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
-    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n};
+    if (G == 0) {
+        if (shared_scans || grid_per_traj) return hipErrorInvalidValue;   // n too large for the window kernel
+        return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
+    }
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj};
     return launch_win(g, src, L, n_scan - 1, n, G, got, s);
 }
 
