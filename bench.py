@@ -114,14 +114,14 @@ def main():
     dr.ctx.set_option("grid_mode", args.grid_mode)
     dr.ctx.set_option("grid_group", args.grid_group)
     pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=dr.dev)
-    gathered = torch.empty((world, 3), dtype=torch.float64, device=dr.dev) if world > 1 else None
+    gathered = torch.empty(world * 3, dtype=torch.float64, device=dr.dev) if world > 1 else None
     L = slam._abi.lib()
 
     def step():
         dr.run(reset_grid=True)
         slam._abi.check(L.slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
         if world > 1:
-            dist.all_gather_into_tensor(gathered, dr.poses[0, -1].contiguous())
+            dist.all_gather_into_tensor(gathered, dr.poses[0, -1].reshape(3).contiguous())
 
     def fence():
         torch.cuda.synchronize()
