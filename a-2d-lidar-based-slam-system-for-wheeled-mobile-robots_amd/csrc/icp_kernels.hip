@@ -151,12 +151,23 @@ __device__ __forceinline__ double dist2(double sx, double sy, double tx, double 
     return fma(dy, dy, dx * dx);
 }
 
-__device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, const Box *__restrict__ boxes, int nblocks,
-                                          int n_tar, double sx, double sy, int seed, bool active, double &best_d2, int &best_j)
+__device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, const Box *__restrict__ boxes,
+                                          const Box *__restrict__ boxes4, int nblocks, int n_tar, double sx, double sy,
+                                          int seed, bool first_iter, bool active, double &best_d2, int &best_j)
 {
     seed = min(max(seed, 0), n_tar - 1);
-    double2 ts = tarL[tslot(seed)];
-    double U = dist2(sx, sy, ts.x, ts.y);
+    double U;
+    if (first_iter) {
+        // no previous match yet: the same-index guess can be far off, so take the best of the
+        // guess's whole block as the bound (16 evaluations that save several block scans)
+        const double2 *t = tarL + (seed >> 4) * kNNStride;
+        U = INFINITY;
+#pragma unroll
+        for (int k = 0; k < kNNBlock; ++k) U = fmin(U, dist2(sx, sy, t[k].x, t[k].y));   // fmin ignores NaN
+    } else {
+        double2 ts = tarL[tslot(seed)];
+        U = dist2(sx, sy, ts.x, ts.y);
+    }
     double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
     double best = INFINITY;
@@ -164,13 +175,21 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
     for (int base = 0; base < nblocks; base += 32) {
         const int cnt = min(32, nblocks - base);
         unsigned mask = 0u;
-        for (int b = 0; b < cnt; ++b) {          // phase A
-            Box bx = boxes[base + b];
-            double dx = fmax(fmax(bx.x0 - sx, sx - bx.x1), 0.0);
-            double dy = fmax(fmax(bx.y0 - sy, sy - bx.y1), 0.0);
-            double lb = fma(dy, dy, dx * dx);
-            mask |= (lb <= bound) ? (1u << b) : 0u;
+        for (int sb = 0; sb < cnt; sb += 4) {    // phase A, two levels: a box of 4 blocks first
+            Box sx4 = boxes4[(base + sb) >> 2];
+            double dx4 = fmax(fmax(sx4.x0 - sx, sx - sx4.x1), 0.0);
+            double dy4 = fmax(fmax(sx4.y0 - sy, sy - sx4.y1), 0.0);
+            if (!__any(fma(dy4, dy4, dx4 * dx4) <= bound)) continue;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {        // boxes[] is padded to a multiple of 4 with empty boxes
+                Box bx = boxes[base + sb + u];
+                double dx = fmax(fmax(bx.x0 - sx, sx - bx.x1), 0.0);
+                double dy = fmax(fmax(bx.y0 - sy, sy - bx.y1), 0.0);
+                double lb = fma(dy, dy, dx * dx);
+                mask |= (lb <= bound) ? (1u << (sb + u)) : 0u;
+            }
         }
+        if (cnt < 32) mask &= (1u << cnt) - 1u;  // padding boxes are never scanned
         while (__any(mask != 0u)) {              // phase B: per-lane scan, lowest marked block first
             if (mask != 0u) {
                 const int blk = base + __ffs((int)mask) - 1;
@@ -197,14 +216,16 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // LDS image of the target: float64 (x, y) pairs padded with NaN points to a whole number
 // of blocks (NaN never wins a comparison), then one bounding box per block.
 __host__ __device__ inline int nn_blocks(int n_tar) { return (n_tar + kNNBlock - 1) / kNNBlock; }
-__host__ __device__ inline int nn_boxes_padded(int n_tar) { return nn_blocks(n_tar) + 1; }
+__host__ __device__ inline int nn_boxes_padded(int n_tar) { return (nn_blocks(n_tar) + 3) / 4 * 4; }   // multiple of 4
+__host__ __device__ inline int nn_boxes4(int n_tar) { return nn_boxes_padded(n_tar) / 4; }
 __host__ __device__ inline size_t nn_lds_bytes(int n_tar)
 {
-    return (size_t)nn_blocks(n_tar) * kNNStride * sizeof(double2) + (size_t)nn_boxes_padded(n_tar) * sizeof(Box);
+    return (size_t)nn_blocks(n_tar) * kNNStride * sizeof(double2) +
+           (size_t)(nn_boxes_padded(n_tar) + nn_boxes4(n_tar)) * sizeof(Box);
 }
 
 template <typename T>
-__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL, Box *boxes)
+__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL, Box *boxes, Box *boxes4)
 {
     const int nb = nn_blocks(n_tar), npad = nb * kNNBlock;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
@@ -223,6 +244,17 @@ __device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *t
         }
         boxes[b] = bx;
     }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nn_boxes4(n_tar); b += blockDim.x) {
+        Box bx = boxes[4 * b];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+            Box o = boxes[4 * b + u];
+            bx.x0 = fmin(bx.x0, o.x0); bx.x1 = fmax(bx.x1, o.x1);
+            bx.y0 = fmin(bx.y0, o.y0); bx.y1 = fmax(bx.y1, o.y1);
+        }
+        boxes4[b] = bx;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -234,7 +266,8 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblocks = nn_blocks(a.n_tar);
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
-    Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [nblocks + 1]
+    Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
+    Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
     double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][5][kMaxWaves]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -244,7 +277,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     const T *src = static_cast<const T *>(a.src) + be * a.src_stride;
     const int n_src = a.n_src, n_tar = a.n_tar;
 
-    stage_target(tar, n_tar, tarL, boxes);
+    stage_target(tar, n_tar, tarL, boxes, boxes4);
 
     double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
     int seed[QPT];
@@ -275,7 +308,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             double d2; int j;
-            nn_search(tarL, boxes, nblocks, n_tar, sx[q], sy[q], seed[q], ok[q], d2, j);   // icp.py:67
+            nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, ok[q], d2, j);   // icp.py:67
             seed[q] = j;                                             // next iteration's guess
             double2 m = tarL[tslot(j)];
             mx[q] = m.x; my[q] = m.y;
@@ -390,15 +423,16 @@ __global__ void __launch_bounds__(256) k_nn(const T *src, const T *tar, int n_sr
     const int nblocks = nn_blocks(n_tar);
     double2 *tarL = reinterpret_cast<double2 *>(smem);
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));
+    Box *boxes4 = boxes + nn_boxes_padded(n_tar);
     const int b = blockIdx.y;
-    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL, boxes);
+    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL, boxes, boxes4);
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = i < n_src;
     const T *s = src + (long)b * 2 * n_src;
     double sx = ok ? ld(s, i) : 0.0, sy = ok ? ld(s, (long)n_src + i) : 0.0;
     double d2; int j;
-    nn_search(tarL, boxes, nblocks, n_tar, sx, sy, i, ok, d2, j);
+    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx, sy, i, true, ok, d2, j);
     if (ok) {
         dist[(long)b * n_src + i] = (d2 < INFINITY) ? sqrt(d2) : 0.0;
         idx[(long)b * n_src + i] = j;
