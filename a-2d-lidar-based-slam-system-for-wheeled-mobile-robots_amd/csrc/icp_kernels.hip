@@ -109,8 +109,8 @@ __device__ __forceinline__ Rigid2 kabsch_from_sums(double cax, double cay, doubl
     double A = w00 + w11, B = w10 - w01;
     double h = sqrt(A * A + B * B);
     Rigid2 r;
-    r.c = h > 0.0 ? A / h : 1.0;
-    r.s = h > 0.0 ? B / h : 0.0;
+    r.c = h == 0.0 ? 1.0 : A / h;           // W = 0: U.Vt of a zero matrix is the identity; NaN propagates
+    r.s = h == 0.0 ? 0.0 : B / h;
     r.tx = cbx - (r.c * cax - r.s * cay);   // t = centroid_B - R.centroid_A (:172)
     r.ty = cby - (r.s * cax + r.c * cay);
     return r;
@@ -380,7 +380,10 @@ template <typename T>
 static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 {
     int qpt = (a.n_src + 1023) / 1024;
-    if (qpt < 2 && a.n_src > 128) qpt = 2;   // two queries per lane: fewer waves per pair, cheaper reductions (measured)
+#ifndef SLAM_ICP_QPT_PREF
+#define SLAM_ICP_QPT_PREF 2
+#endif
+    if (qpt < SLAM_ICP_QPT_PREF && a.n_src > 64 * SLAM_ICP_QPT_PREF) qpt = SLAM_ICP_QPT_PREF;   // queries per lane: fewer waves per pair, cheaper reductions (measured)
     size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);

@@ -24,6 +24,14 @@ from . import _abi
 from .param import get_param
 
 
+def _check_finite(T):
+    """The reference takes numpy.linalg.svd of W (icp.py:161), which raises LinAlgError when a
+    NaN / inf coordinate (e.g. an unclipped inf range, W7 icp.py:192-194) reached it; the
+    device propagates the NaN into T instead, so the same exception is raised here."""
+    if not np.all(np.isfinite(T)):
+        raise np.linalg.LinAlgError("SVD did not converge")
+
+
 def _soa(points_nx2):
     """[N,2] (any strides, e.g. a transposed view) -> contiguous float64 [2,N]."""
     a = np.asarray(points_nx2, dtype=np.float64)
@@ -71,6 +79,7 @@ class ICP:
                                              src.shape[1], _abi.F64, 0, 0, None, int(max_iter), float(tolerance),
                                              _abi.ptr(T), _abi.ptr(it), _abi.ptr(err)))
         self.last_iters, self.last_mean_error = int(it[0]), float(err[0])
+        _check_finite(T)
         return T
 
     def findNearest(self, src, tar):
@@ -91,6 +100,7 @@ class ICP:
             raise ValueError("operands could not be broadcast together with shapes %r %r" % (s.T.shape, t.T.shape))
         T = np.empty((3, 3), dtype=np.float64)
         _abi.check(_abi.lib().slam_kabsch2d(self._ctx.handle, _abi.ptr(s), _abi.ptr(t), 1, s.shape[1], _abi.ptr(T)))
+        _check_finite(T)
         return T
 
     def laserToNumpy(self, msg):

@@ -1,0 +1,124 @@
+"""Randomised and degenerate-input parity tests of the HIP path against the C oracle
+(hypothesis drives the shapes and seeds; every example is one or two C-ABI calls)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from conftest import pkg
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+FTOL = 1e-9
+SET = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.fixture(scope="module")
+def slam():
+    p = pkg()
+    p._abi.default_context()
+    return p
+
+
+@settings(**SET)
+@given(n=st.integers(1, 700), m=st.integers(1, 700), seed=st.integers(0, 2**31 - 1), scale=st.sampled_from([1e-3, 1.0, 50.0]),
+       offset=st.sampled_from([0.0, 7.5, -1e4]))
+def test_nn_matches_exhaustive_scan(slam, n, m, seed, scale, offset):
+    rng = np.random.default_rng(seed)
+    tar = rng.normal(0, scale, size=(m, 2)) + offset
+    # duplicates and exact ties on purpose: quantised coordinates
+    if seed % 3 == 0:
+        tar = np.round(tar / scale * 4) * scale / 4
+    src = rng.normal(0, scale, size=(n, 2)) + offset
+    if seed % 5 == 0:
+        src[:: max(1, n // 7)] = tar[rng.integers(0, m, size=len(src[:: max(1, n // 7)]))]   # exact hits
+    d, i = slam.ICP().findNearest(src, tar)
+    od, oi = co.find_nearest(src, tar)
+    assert np.array_equal(i, oi)                     # lowest index on ties, bit-exact
+    assert np.max(np.abs(d - od)) <= 1e-12 * max(1.0, scale)
+
+
+@settings(**SET)
+@given(n=st.integers(3, 400), m=st.integers(8, 400), seed=st.integers(0, 2**31 - 1), max_iter=st.integers(0, 12),
+       tol=st.sampled_from([0.0, 1e-3, 1e-1]))
+def test_icp_process_random_clouds(slam, n, m, seed, max_iter, tol):
+    # (m >= 8: when every source point matches the SAME target point the cross-covariance is pure
+    # rounding noise in the reference itself and the rotation is arbitrary; see test_icp_degenerate_inputs
+    # for the exactly-representable version of that case)
+    rng = np.random.default_rng(seed)
+    tar = np.ascontiguousarray(rng.normal(0, 3, size=(1, 2, m)))
+    src = np.ascontiguousarray(rng.normal(0, 3, size=(1, 2, n)))
+    T, it, err = slam.icp_batch_host(tar, src, max_iter, tol)
+    oT, oit, oerr = co.icp_batch(tar, src, max_iter, tol)
+    assert it[0] == oit[0]
+    assert np.max(np.abs(T - oT)) < 1e-8 and abs(err[0] - oerr[0]) < FTOL
+
+
+def test_icp_degenerate_inputs(slam):
+    icp = slam.ICP()
+    ones = lambda a: np.vstack([a, np.ones((1, a.shape[1]))])
+    # identical clouds: identity after the first convergence check
+    pts = np.random.default_rng(0).normal(0, 2, size=(2, 50))
+    T = icp.process(ones(pts), ones(pts))
+    assert np.max(np.abs(T - np.eye(3))) < 1e-12 and icp.last_iters == 1 or icp.last_iters == 2
+    # every source point matches the same target point: W = 0 exactly -> R = I (as numpy's svd of zeros)
+    tar = np.array([[0.0, 100.0, 200.0], [0.0, 100.0, 200.0]])
+    src = np.array([[0.1, -0.2, 0.3], [0.2, 0.1, -0.3]])
+    T = icp.process(ones(tar), ones(src))
+    oT, oit, _ = co.icp_process(tar, src, 30, 0.001)
+    assert np.max(np.abs(T - oT)) < FTOL and icp.last_iters == oit and abs(T[0, 0] - 1.0) < 1e-15
+    # single points
+    T = icp.process(ones(np.array([[3.0], [4.0]])), ones(np.array([[1.0], [1.0]])))
+    assert np.max(np.abs(T - np.array([[1, 0, 2.0], [0, 1, 3.0], [0, 0, 1]]))) < 1e-12
+    # NaN / inf coordinates in the source (W7 laserToNumpy does not clip inf): numpy's svd raises in the
+    # reference; the device propagates NaN exactly as the C oracle does and the class raises the same error
+    tar = np.random.default_rng(1).normal(0, 2, size=(2, 40))
+    src = tar[:, ::2].copy()
+    src[0, 3] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        icp.process(ones(tar), ones(src))
+    T, it, _ = slam.icp_batch_host(tar[None], src[None], 30, 0.001)
+    oT, oit, _ = co.icp_process(tar, src, 30, 0.001)
+    assert it[0] == oit and np.array_equal(np.isnan(T[0]), np.isnan(oT))
+    src[0, 3] = np.inf
+    with pytest.raises(np.linalg.LinAlgError):
+        icp.process(ones(tar), ones(src))
+    # NaN target points never win
+    tar2 = tar.copy(); tar2[:, 5] = np.nan
+    d, i = icp.findNearest(src[:, :10].T.copy() * 0 + tar[:, 5:6].T, tar2.T.copy())
+    assert np.all(i != 5)
+
+
+@settings(**SET)
+@given(n=st.integers(1, 500), seed=st.integers(0, 2**31 - 1), xw=st.sampled_from([37, 200, 400]), yw=st.sampled_from([64, 200, 301]),
+       scale=st.sampled_from([10.0, 20.0, 50.0]), rmax=st.sampled_from([0.2, 6.0, 40.0]), batch=st.integers(1, 5))
+def test_grid_update_random_scans(slam, n, seed, xw, yw, scale, rmax, batch):
+    rng = np.random.default_rng(seed)
+    off_x, off_y = xw / (2 * scale), yw / (2 * scale)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y)
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    cx, cy = rng.uniform(-off_x * 1.3, off_x * 1.3, batch), rng.uniform(-off_y * 1.3, off_y * 1.3, batch)
+    ang = rng.uniform(-np.pi, np.pi, (batch, n))
+    d = rng.uniform(0, rmax, (batch, n))
+    ox, oy = cx[:, None] + np.cos(ang) * d, cy[:, None] + np.sin(ang) * d
+    if seed % 4 == 0:
+        ox[0, : max(1, n // 5)] = np.inf                       # skipped beams
+    if seed % 7 == 0:
+        ox[-1, -1], oy[-1, -1] = cx[-1], cy[-1]                # zero-length ray
+    g.update_host(ox, oy, cx, cy)
+    for b in range(batch):
+        og.update(ox[b], oy[b], cx[b], cy[b])
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+    assert np.array_equal(r["pmap"], og.pmap) and g.visits() == og.visits
+    g.close()
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2**31 - 1), B=st.integers(1, 300), span=st.sampled_from([3, 50, 3000]))
+def test_bresenham_random_lines(slam, seed, B, span):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(-span, span + 1, size=(B, 2))
+    e = s + rng.integers(-span, span + 1, size=(B, 2))
+    for p, a, b in zip(slam.rasterize(s, e), s, e):
+        assert np.array_equal(p, co.bresenham(a, b))
