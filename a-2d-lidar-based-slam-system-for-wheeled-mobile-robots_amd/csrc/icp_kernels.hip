@@ -44,6 +44,16 @@ __device__ __forceinline__ void st(__half *p, long i, double v)
     p[i] = __float2half_rn(f);
 }
 
+// value of x after a store to / load from storage type T (the rounding a point buffer applies)
+__device__ __forceinline__ double round_as(double v, const double *) { return v; }
+__device__ __forceinline__ double round_as(double v, const float *) { return (double)(float)v; }
+__device__ __forceinline__ double round_as(double v, const __half *)
+{
+    __half h;
+    st(&h, 0, v);
+    return (double)__half2float(h);
+}
+
 // Wave-wide sum of a double, result in every lane, without touching LDS: four DPP
 // exchange steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror, row mirror;
 // addition is commutative, so both partners of an exchange hold the same bits), then the
@@ -224,13 +234,32 @@ __host__ __device__ inline size_t nn_lds_bytes(int n_tar)
            (size_t)(nn_boxes_padded(n_tar) + nn_boxes4(n_tar)) * sizeof(Box);
 }
 
+// A cloud read either from a point buffer or straight from a raw scan (laserToNumpy fused:
+// slam_ekf.py:115-123, x = cos(angle_i) * r with inf -> 30 m, rounded to the buffer type T).
 template <typename T>
-__device__ __forceinline__ void stage_target(const T *tar, int n_tar, double2 *tarL, Box *boxes, Box *boxes4)
+struct Cloud {
+    const T *pts;              // [2][n] or null
+    const float *ranges;       // [n] or null
+    const double *cos_t, *sin_t;
+    int n;
+    __device__ __forceinline__ double2 at(int j) const
+    {
+        if (ranges) {
+            double r = (double)ranges[j];
+            if (r == INFINITY) r = 30.0;
+            return make_double2(round_as(cos_t[j] * r, (const T *)nullptr), round_as(sin_t[j] * r, (const T *)nullptr));
+        }
+        return make_double2(ld(pts, j), ld(pts, (long)n + j));
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, double2 *tarL, Box *boxes, Box *boxes4)
 {
     const int nb = nn_blocks(n_tar), npad = nb * kNNBlock;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     for (int j = threadIdx.x; j < npad; j += blockDim.x)
-        tarL[tslot(j)] = j < n_tar ? make_double2(ld(tar, j), ld(tar, (long)n_tar + j)) : make_double2(qnan, qnan);
+        tarL[tslot(j)] = j < n_tar ? tar.at(j) : make_double2(qnan, qnan);
     __syncthreads();
     for (int b = threadIdx.x; b < nn_boxes_padded(n_tar); b += blockDim.x) {
         Box bx{INFINITY, -INFINITY, INFINITY, -INFINITY};            // stays empty for the padding boxes
@@ -273,9 +302,15 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     const long be = (long)b + (a.ppt ? b / a.ppt : 0);
-    const T *tar = static_cast<const T *>(a.tar) + be * a.tar_stride;
-    const T *src = static_cast<const T *>(a.src) + be * a.src_stride;
     const int n_src = a.n_src, n_tar = a.n_tar;
+    Cloud<T> tar{nullptr, nullptr, a.cos_t, a.sin_t, n_tar}, src{nullptr, nullptr, a.cos_t, a.sin_t, n_src};
+    if (a.ranges) {
+        tar.ranges = a.ranges + be * a.tar_scan_stride;
+        src.ranges = a.ranges + be * a.src_scan_stride + n_tar;      // the scan after the target's
+    } else {
+        tar.pts = static_cast<const T *>(a.tar) + be * a.tar_stride;
+        src.pts = static_cast<const T *>(a.src) + be * a.src_stride;
+    }
 
     stage_target(tar, n_tar, tarL, boxes, boxes4);
 
@@ -286,7 +321,8 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     for (int q = 0; q < QPT; ++q) {
         int i = tid + q * blockDim.x;
         ok[q] = i < n_src;
-        double x = ok[q] ? ld(src, i) : 0.0, y = ok[q] ? ld(src, (long)n_src + i) : 0.0;
+        double2 pt = ok[q] ? src.at(i) : make_double2(0.0, 0.0);
+        double x = pt.x, y = pt.y;
         if (a.prior) {
             const double *p = a.prior + 6 * (long)b;
             double xp = p[0] * x + p[1] * y + p[2];
@@ -428,7 +464,7 @@ __global__ void __launch_bounds__(256) k_nn(const T *src, const T *tar, int n_sr
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));
     Box *boxes4 = boxes + nn_boxes_padded(n_tar);
     const int b = blockIdx.y;
-    stage_target(tar + (long)b * 2 * n_tar, n_tar, tarL, boxes, boxes4);
+    stage_target(Cloud<T>{tar + (long)b * 2 * n_tar, nullptr, nullptr, nullptr, n_tar}, n_tar, tarL, boxes, boxes4);
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = i < n_src;

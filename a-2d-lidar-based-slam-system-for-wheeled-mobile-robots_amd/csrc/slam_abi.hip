@@ -409,6 +409,7 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     REQUIRE(n_tar <= 8192, "n_tar too large for the LDS-resident target (max 8192 points)");
     IcpArgs a;
     a.tar = tar; a.src = src; a.prior = prior;
+    a.ranges = nullptr; a.cos_t = a.sin_t = nullptr; a.tar_scan_stride = a.src_scan_stride = 0;
     a.tar_stride = tar_shared ? 0 : 2L * n_tar;
     a.src_stride = src_shared ? 0 : 2L * n_src;
     a.ppt = 0;
@@ -678,7 +679,8 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
                     void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
 {
     TRY(use(c));
-    REQUIRE(ranges && cos_t && sin_t && pose0 && pts_ws && poses_out, "null pointer");
+    REQUIRE(ranges && cos_t && sin_t && pose0 && poses_out, "null pointer");
+    (void)pts_ws;   // kept in the ABI; the point buffers are no longer materialised
     REQUIRE(L > 0 && n_scan >= 2 && n > 0, "need L > 0, n_scan >= 2, n > 0");
     REQUIRE(max_iter >= 0, "max_iter must be >= 0");
     size_t ds = dtype_size(dtype);
@@ -692,15 +694,13 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         T = carve<double>(c->scratch, (size_t)pairs * 9);
     }
     {
-        Timed t(c, SLAM_K_POINTS);
-        HIPCHK(launch_scan_to_points(ranges, cos_t, sin_t, (long)L * n_scan * n, n, 1, dtype, pts_ws, c->stream));
-    }
-    {
+        // polar -> Cartesian is fused into the ICP kernel: scan k-1 / k of stream l are read as raw
+        // ranges and turned into points (of storage type `dtype`) in registers
         IcpArgs a;
-        a.tar = pts_ws;
-        a.src = static_cast<const char *>(pts_ws) + 2 * (size_t)n * ds;   // scan k is the source, k-1 the target
-        a.prior = nullptr;
-        a.tar_stride = a.src_stride = 2L * n;
+        a.tar = a.src = nullptr; a.prior = nullptr;
+        a.ranges = ranges; a.cos_t = cos_t; a.sin_t = sin_t;
+        a.tar_scan_stride = a.src_scan_stride = n;
+        a.tar_stride = a.src_stride = 0;
         a.ppt = n_scan - 1;
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
@@ -763,7 +763,8 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
                        void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
 {
     TRY(use(c));
-    REQUIRE(ranges2 && cos_t && sin_t && pose_prev && pts_ws && poses_out && T_out, "null pointer");
+    REQUIRE(ranges2 && cos_t && sin_t && pose_prev && poses_out && T_out, "null pointer");
+    (void)pts_ws;   // kept in the ABI; the point buffers are no longer materialised
     REQUIRE(P > 0 && n > 0 && n <= 8192, "need P > 0 and 0 < n <= 8192");
     REQUIRE(max_iter >= 0, "max_iter must be >= 0");
     size_t ds = dtype_size(dtype);
@@ -771,15 +772,11 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
     REQUIRE(!grid || grid->d.G >= P, "the grid object needs one map per particle");
     REQUIRE(!grid || P <= 65535, "at most 65535 particles per call when ray casting");
     {
-        Timed t(c, SLAM_K_POINTS);
-        HIPCHK(launch_scan_to_points(ranges2, cos_t, sin_t, 2L * n, n, 1, dtype, pts_ws, c->stream));
-    }
-    {
         IcpArgs a;
-        a.tar = pts_ws;
-        a.src = static_cast<const char *>(pts_ws) + 2 * (size_t)n * ds;
-        a.prior = prior;
-        a.tar_stride = a.src_stride = 0;   // every hypothesis matches the same scan pair
+        a.tar = a.src = nullptr; a.prior = prior;
+        a.ranges = ranges2; a.cos_t = cos_t; a.sin_t = sin_t;
+        a.tar_scan_stride = a.src_scan_stride = 0;   // every hypothesis matches the same scan pair
+        a.tar_stride = a.src_stride = 0;
         a.ppt = 0;
         a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;

@@ -17,7 +17,14 @@ enum : int { kStatusNaN = 1, kStatusOverflow = 2 };
 
 // ---- ICP ---------------------------------------------------------------------------
 struct IcpArgs {
-    const void *tar, *src;     // point buffers, [2][n] per set, storage type = template T
+    // Either point buffers ...
+    const void *tar, *src;     // [2][n] per set, storage type = template T
+    // ... or raw scans (fused polar->Cartesian, used by the replay / particle pipelines): scan k
+    // of a stream is the source, scan k-1 the target; the points are formed in registers with the
+    // same arithmetic as k_scan_to_points (one multiply, then rounding to T) and never touch HBM.
+    const float *ranges;       // nullable; [.. scans ..][n]
+    const double *cos_t, *sin_t;
+    long tar_scan_stride, src_scan_stride;   // floats between consecutive pairs' scans (0: shared)
     const double *prior;       // nullable [B][6]
     long tar_stride, src_stride;  // elements between consecutive sets (0: shared)
     int ppt;                   // replay addressing: pairs per trajectory (0: plain batch)

@@ -190,7 +190,6 @@ class DeviceReplay:
             r = r[None]
         self.L, self.n_scan, self.n = r.shape
         self.code = _abi.DTYPES[dtype]
-        tdt = {_abi.F64: torch.float64, _abi.F32: torch.float32, _abi.F16: torch.float16}[self.code]
         ct, st = _abi.trig_tables(angle_min, angle_max, self.n)
         self.ranges = torch.from_numpy(r).to(self.dev)
         self.cos_t = torch.from_numpy(ct).to(self.dev)
@@ -198,7 +197,6 @@ class DeviceReplay:
         p0 = np.zeros((self.L, 3)) if pose0 is None else np.asarray(pose0, dtype=np.float64).reshape(self.L, 3)
         self.pose0 = torch.from_numpy(np.ascontiguousarray(p0)).to(self.dev)
         pairs = self.L * (self.n_scan - 1)
-        self.pts = torch.empty(self.L * self.n_scan * 2 * self.n, dtype=tdt, device=self.dev)
         self.poses = torch.empty((self.L, self.n_scan - 1, 3), dtype=torch.float64, device=self.dev)
         self.T = torch.empty((pairs, 9), dtype=torch.float64, device=self.dev)
         self.iters = torch.empty(pairs, dtype=torch.int32, device=self.dev)
@@ -220,7 +218,7 @@ class DeviceReplay:
             self.ctx.handle, self.ranges.data_ptr(), self.cos_t.data_ptr(), self.sin_t.data_ptr(), self.L, self.n_scan,
             self.n, self.code, self.max_iter, self.tol, self.pose0.data_ptr(),
             self.grid._h if self.grid is not None else None, self.got.data_ptr() if self.got is not None else None,
-            self.pts.data_ptr(), self.poses.data_ptr(), self.T.data_ptr(), self.iters.data_ptr()))
+            None, self.poses.data_ptr(), self.T.data_ptr(), self.iters.data_ptr()))
 
     @property
     def scans_per_run(self):

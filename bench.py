@@ -11,8 +11,8 @@ scans: every 5th message of a 10 Hz stream, as the reference's callback decimate
 (W12m/slam_ekf.py:65-68), so consecutive processed scans are 0.5 s apart.  ICP parameters
 are the ones effective in the W12 mapping node, max_iter 30 / tolerance 1e-3
 (W12m/icp.py:21-25).  One "step" = one pass of the hot path over that batch, inputs
-(float32 ranges) already resident in HBM: map reset -> polar->Cartesian -> 999 ICP solves
--> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of `value`: processed
+(float32 ranges) already resident in HBM: map reset -> 999 ICP solves (polar->Cartesian
+fused in) -> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of `value`: processed
 scans per second (one ICP.process + one Mapping.update each), summed over all ranks.
 
 With N > 1 every rank replays its own trajectory (seed 1 + rank; weak scaling, no
@@ -157,12 +157,15 @@ def main():
     dom_ms, dom_n = fam[dom]
     avg_s = dom_ms / dom_n * 1e-3
     psz = {"f64": 8, "f32": 4, "f16": 2}[args.points]
-    icp_bytes = scans_per_step * ((2 * args.beams) * 2 * psz + 72)        # (n_src+n_tar)*2*s + 72 per scan
+    # SURVEY 8(d) prices a pair at (n_src+n_tar)*2*s + 72 B for point buffers of s bytes per coordinate.
+    # Since polar->Cartesian is fused into k_icp the kernel reads the raw float32 ranges instead
+    # (4 B per point) and no point buffer exists: (n_src+n_tar)*4 + 72 B per pair.
+    icp_bytes = scans_per_step * ((2 * args.beams) * 4 + 72)
     grid_bytes = 9 * visits                                               # 9 B per in-bounds cell visit
     alg_bytes = {"icp": icp_bytes, "grid": grid_bytes,
-                 "points": scans_per_step * args.beams * (4 + 2 * psz), "compose": scans_per_step * (72 + 24),
+                 "compose": scans_per_step * (72 + 24),
                  "finalize": args.grid * args.grid * 9}.get(dom, 0)
-    kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "points": "k_scan_to_points", "compose": "k_pose_compose",
+    kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "compose": "k_pose_compose",
              "finalize": "k_grid_finalize"}.get(dom, dom)
     if dom == "grid" and args.grid_mode == 1:
         kname = "k_grid_update_win"

@@ -174,8 +174,9 @@ int slam_replay(slam_ctx *ctx, const float *ranges, const double *cos_t, const d
                 int n_scan, int n, int dtype, int max_iter, double tol, const double *pose0,
                 slam_grid *grid, const int32_t *grid_of_traj, double *poses_out, double *T_out,
                 int32_t *iters_out);
-/* Device form: additionally needs a caller-provided point buffer pts_ws of
- * L*n_scan*2*n elements of `dtype`. */
+/* Device form.  pts_ws is unused (may be NULL): polar->Cartesian is fused into the ICP
+ * kernel, which forms the points of storage type `dtype` in registers; the parameter is
+ * kept for ABI stability. */
 int slam_replay_dev(slam_ctx *ctx, const float *ranges, const double *cos_t, const double *sin_t, int L,
                     int n_scan, int n, int dtype, int max_iter, double tol, const double *pose0,
                     slam_grid *grid, const int32_t *grid_of_traj, void *pts_ws, double *poses_out,
@@ -194,7 +195,7 @@ int slam_replay_dev(slam_ctx *ctx, const float *ranges, const double *cos_t, con
 int slam_particles(slam_ctx *ctx, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
                    const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
                    double *poses_out, double *T_out, int32_t *iters_out);
-/* Device form: pts_ws holds 4*n elements of `dtype`; T_out is required. */
+/* Device form: T_out is required; pts_ws is unused (may be NULL), as in slam_replay_dev. */
 int slam_particles_dev(slam_ctx *ctx, const float *ranges2, const double *cos_t, const double *sin_t, int n, int dtype,
                        const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
                        void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out);

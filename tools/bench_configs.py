@@ -40,7 +40,6 @@ def particles(slam, torch, P, steps, warmup):
     ranges2, cos_t, sin_t = d(rep.ranges.astype(np.float32)), d(ct), d(st)
     prior = d(slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2)).reshape(P, 6))
     pose_prev = d(np.zeros((P, 3)))
-    pts = torch.empty(4 * n, dtype=torch.float64, device=dev)
     poses = torch.empty((P, 3), dtype=torch.float64, device=dev)
     T = torch.empty((P, 9), dtype=torch.float64, device=dev)
     iters = torch.empty(P, dtype=torch.int32, device=dev)
@@ -50,7 +49,7 @@ def particles(slam, torch, P, steps, warmup):
 
     def step():
         A.check(L.slam_particles_dev(ctx.handle, ranges2.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), n, A.F64,
-                                     prior.data_ptr(), pose_prev.data_ptr(), P, 30, 1e-3, grid._h, pts.data_ptr(),
+                                     prior.data_ptr(), pose_prev.data_ptr(), P, 30, 1e-3, grid._h, None,
                                      poses.data_ptr(), T.data_ptr(), iters.data_ptr()))
         A.check(L.slam_grid_finalize_dev(ctx.handle, grid._h, pmap.data_ptr()))
 
