@@ -8,6 +8,7 @@ zjwzcx/A-2D-LiDAR-based-SLAM-System-for-Wheeled-Mobile-Robots:
     Mapping    update -> pmap
     bresenham  (start, end).path
     SLAM_EKF   laserCallback glue (scan matching + map building; no EKF, no landmarks)
+    Localization  updateMap / laserEstimation / calc_map_observation (scan-to-map, W9)
 
 plus the batched forms used by bench.py (``replay``) and the multi-GPU sharding helper
 (``dist``).  Importing the package never computes anything; every operator raises if
@@ -17,11 +18,12 @@ from . import _abi, param, synthetic
 from ._abi import Context, LibraryMissing, SlamError, default_context
 from .bresenham import bresenham, rasterize
 from .icp import ICP, scan_to_pc
+from .localization import Localization
 from .mapping import Mapping
 from .replay import DeviceGrid, DeviceReplay, icp_batch_host, particles_host, prior_matrices, replay_host
 from .slam_ekf import SLAM_EKF
 from .synthetic import LaserScan
 
-__all__ = ["ICP", "Mapping", "bresenham", "rasterize", "SLAM_EKF", "LaserScan", "Context", "default_context",
+__all__ = ["ICP", "Mapping", "Localization", "bresenham", "rasterize", "SLAM_EKF", "LaserScan", "Context", "default_context",
            "DeviceGrid", "DeviceReplay", "replay_host", "icp_batch_host", "particles_host", "prior_matrices", "scan_to_pc", "SlamError",
            "LibraryMissing", "param", "synthetic"]

@@ -826,4 +826,144 @@ int slam_particles(slam_ctx *c, const float *ranges2, const double *cos_t, const
     return check_status_sync(c);
 }
 
+/* ---- scan-to-map observation ------------------------------------- */
+
+int slam_map_obstacles(slam_ctx *c, const int8_t *map, int width, int height, int wire_layout, double resolution,
+                       double origin_x, double origin_y, double *ox, double *oy, int cap, int *count_out)
+{
+    TRY(use(c));
+    REQUIRE(map && ox && oy && count_out, "null pointer");
+    REQUIRE(width > 0 && height > 0 && cap >= 0, "bad sizes");
+    size_t cells = (size_t)width * height;
+    TRY(arena_reserve(c, c->staging, align_up(cells) + 2 * align_up((size_t)cap * 8) + 1024));
+    int8_t *d_m = carve<int8_t>(c->staging, cells);
+    double *d_x = carve<double>(c->staging, cap), *d_y = carve<double>(c->staging, cap);
+    int *d_k = carve<int>(c->staging, 1);
+    H2D(d_m, map, cells);
+    HIPCHK(launch_map_obstacles(d_m, width, height, wire_layout, resolution, origin_x, origin_y, d_x, d_y, cap, d_k, c->stream));
+    int k = 0;
+    D2H(&k, d_k, sizeof(int));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *count_out = k;
+    int got = k < cap ? k : cap;
+    if (got > 0) {
+        D2H(ox, d_x, (size_t)got * 8);
+        D2H(oy, d_y, (size_t)got * 8);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SLAM_OK;
+}
+
+int slam_map_obstacles_dev(slam_ctx *c, const int8_t *map, int width, int height, int wire_layout, double resolution,
+                           double origin_x, double origin_y, double *ox, double *oy, int cap, int *count_dev)
+{
+    TRY(use(c));
+    REQUIRE(map && ox && oy && count_dev, "null pointer");
+    REQUIRE(width > 0 && height > 0 && cap >= 0, "bad sizes");
+    HIPCHK(launch_map_obstacles(map, width, height, wire_layout, resolution, origin_x, origin_y, ox, oy, cap, count_dev, c->stream));
+    return SLAM_OK;
+}
+
+int slam_virtual_scan_dev(slam_ctx *c, const double *ox, const double *oy, int K, const double *poses, int B,
+                          double angle_min, double angle_increment, int n, double *ranges_out)
+{
+    TRY(use(c));
+    REQUIRE((K == 0 || (ox && oy)) && poses && ranges_out, "null pointer");
+    REQUIRE(K >= 0 && B > 0 && n > 0 && B <= 65535, "bad sizes");
+    REQUIRE(angle_increment != 0.0 && std::isfinite(angle_increment) && std::isfinite(angle_min), "bad angles");
+    HIPCHK(launch_virtual_scan(ox, oy, K, poses, B, angle_min, angle_increment, n, ranges_out, c->stream));
+    return SLAM_OK;
+}
+
+int slam_virtual_scan(slam_ctx *c, const double *ox, const double *oy, int K, const double *poses, int B, double angle_min,
+                      double angle_increment, int n, double *ranges_out)
+{
+    TRY(use(c));
+    REQUIRE((K == 0 || (ox && oy)) && poses && ranges_out, "null pointer");
+    REQUIRE(K >= 0 && B > 0 && n > 0, "bad sizes");
+    TRY(arena_reserve(c, c->staging, 2 * align_up((size_t)K * 8) + align_up((size_t)B * 24) + align_up((size_t)B * n * 8) + 2048));
+    double *d_x = carve<double>(c->staging, K), *d_y = carve<double>(c->staging, K);
+    double *d_p = carve<double>(c->staging, (size_t)B * 3), *d_r = carve<double>(c->staging, (size_t)B * n);
+    if (K) { H2D(d_x, ox, (size_t)K * 8); H2D(d_y, oy, (size_t)K * 8); }
+    H2D(d_p, poses, (size_t)B * 24);
+    TRY(slam_virtual_scan_dev(c, d_x, d_y, K, d_p, B, angle_min, angle_increment, n, d_r));
+    D2H(ranges_out, d_r, (size_t)B * n * 8);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_scan_to_points_f64_dev(slam_ctx *c, const double *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                                double *pts_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pts_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "bad sizes");
+    HIPCHK(launch_ranges64_to_points(ranges, cos_t, sin_t, B, n, pts_out, c->stream));
+    return SLAM_OK;
+}
+
+int slam_scan_to_points_f64(slam_ctx *c, const double *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                            double *pts_out)
+{
+    TRY(use(c));
+    REQUIRE(ranges && cos_t && sin_t && pts_out, "null pointer");
+    REQUIRE(B > 0 && n > 0, "bad sizes");
+    TRY(arena_reserve(c, c->staging, align_up((size_t)B * n * 8) + 2 * align_up((size_t)n * 8) + align_up((size_t)B * 2 * n * 8) + 2048));
+    double *d_r = carve<double>(c->staging, (size_t)B * n);
+    double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
+    double *d_p = carve<double>(c->staging, (size_t)B * 2 * n);
+    H2D(d_r, ranges, (size_t)B * n * 8);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_s, sin_t, (size_t)n * 8);
+    TRY(slam_scan_to_points_f64_dev(c, d_r, d_c, d_s, B, n, d_p));
+    D2H(pts_out, d_p, (size_t)B * 2 * n * 8);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_map_observation_dev(slam_ctx *c, const double *ox, const double *oy, int K, const double *poses, const double *src,
+                             int B, int n, int src_shared, const double *cos_t, const double *sin_t, double angle_min,
+                             double angle_increment, int max_iter, double tol, double *vranges_ws, double *vpts_ws,
+                             double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE(poses && src && cos_t && sin_t && vranges_ws && vpts_ws && T_out, "null pointer");
+    REQUIRE(B > 0 && n > 0 && n <= 8192, "bad sizes");
+    TRY(slam_virtual_scan_dev(c, ox, oy, K, poses, B, angle_min, angle_increment, n, vranges_ws));
+    HIPCHK(launch_ranges64_to_points(vranges_ws, cos_t, sin_t, B, n, vpts_ws, c->stream));
+    return slam_icp_batch_dev(c, vpts_ws, src, B, n, n, SLAM_F64, 0, src_shared, nullptr, max_iter, tol, T_out, iters_out,
+                              nullptr);
+}
+
+int slam_map_observation(slam_ctx *c, const double *ox, const double *oy, int K, const double *poses, const double *src,
+                         int B, int n, int src_shared, const double *cos_t, const double *sin_t, double angle_min,
+                         double angle_increment, int max_iter, double tol, double *T_out, int32_t *iters_out)
+{
+    TRY(use(c));
+    REQUIRE((K == 0 || (ox && oy)) && poses && src && cos_t && sin_t && T_out, "null pointer");
+    REQUIRE(K >= 0 && B > 0 && n > 0, "bad sizes");
+    size_t bs = (size_t)(src_shared ? 1 : B) * 2 * n * 8;
+    TRY(arena_reserve(c, c->staging, 2 * align_up((size_t)K * 8) + align_up((size_t)B * 24) + align_up(bs) + 2 * align_up((size_t)n * 8) +
+                                         align_up((size_t)B * n * 8) + align_up((size_t)B * 2 * n * 8) + align_up((size_t)B * 72) +
+                                         align_up((size_t)B * 4) + 4096));
+    double *d_x = carve<double>(c->staging, K), *d_y = carve<double>(c->staging, K);
+    double *d_p = carve<double>(c->staging, (size_t)B * 3);
+    double *d_s = carve<double>(c->staging, bs / 8);
+    double *d_c = carve<double>(c->staging, n), *d_sn = carve<double>(c->staging, n);
+    double *d_vr = carve<double>(c->staging, (size_t)B * n), *d_vp = carve<double>(c->staging, (size_t)B * 2 * n);
+    double *d_T = carve<double>(c->staging, (size_t)B * 9);
+    int32_t *d_it = carve<int32_t>(c->staging, B);
+    if (K) { H2D(d_x, ox, (size_t)K * 8); H2D(d_y, oy, (size_t)K * 8); }
+    H2D(d_p, poses, (size_t)B * 24);
+    H2D(d_s, src, bs);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_sn, sin_t, (size_t)n * 8);
+    TRY(slam_map_observation_dev(c, d_x, d_y, K, d_p, d_s, B, n, src_shared, d_c, d_sn, angle_min, angle_increment, max_iter,
+                                 tol, d_vr, d_vp, d_T, d_it));
+    D2H(T_out, d_T, (size_t)B * 72);
+    if (iters_out) D2H(iters_out, d_it, (size_t)B * 4);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
 }  // extern "C"

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "slam_hip.h"
 
@@ -77,5 +78,13 @@ hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStr
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);
 hipError_t launch_bresenham(const int32_t *starts, const int32_t *ends, int B, const int64_t *offsets,
                             int32_t *lens, int32_t *cells, hipStream_t s);
+
+// ---- scan-to-map observation ---------------------------------------
+hipError_t launch_map_obstacles(const int8_t *map, int width, int height, int wire, double resolution, double origin_x,
+                                double origin_y, double *ox, double *oy, int cap, int *count, hipStream_t s);
+hipError_t launch_virtual_scan(const double *ox, const double *oy, int K, const double *poses, int B, double angle_min,
+                               double angle_increment, int n, double *ranges, hipStream_t s);
+hipError_t launch_ranges64_to_points(const double *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                                     double *pts, hipStream_t s);
 
 }  // namespace slam

@@ -89,10 +89,10 @@ def load_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(p))
-        return d.get(kernel, {}).get("hbm_bytes_per_launch"), d.get(kernel, {}).get("source")
+        d = json.load(open(p)).get(kernel, {})
+        return d.get("hbm_bytes_per_launch"), d.get("source"), d.get("valu_busy_frac")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -169,10 +169,11 @@ def main():
              "finalize": "k_grid_finalize"}.get(dom, dom)
     if dom == "grid" and args.grid_mode == 1:
         kname = "k_grid_update_win"
-    traffic, tsrc = load_traffic(kname)
+    traffic, tsrc, valu_busy = load_traffic(kname)
     achieved = alg_bytes / avg_s / 1e9
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                "valu_busy_frac_pmc": valu_busy,   # SQ_ACTIVE_INST_VALU share of the kernel's SIMD cycles (profiles/)
                 "avg_launch_ms": dom_ms / dom_n, "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms_per_step": {k: fam[k][0] / args.steps for k in ms}}
     # ICP is VALU-bound, not HBM-bound.  The figure below counts the distance

@@ -200,6 +200,49 @@ int slam_particles_dev(slam_ctx *ctx, const float *ranges2, const double *cos_t,
                        const double *prior, const double *pose_prev, int P, int max_iter, double tol, slam_grid *grid,
                        void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out);
 
+/* ---- scan-to-map observation -------------------------------------- */
+/* W9 = "W9_Fusion Localization (LiDAR Odometry)/course_agv_slam/scripts".
+ * Replaces the obstacle extraction of Localization.updateMap (W9/localization.py:54-60):
+ * cells > 20 or < -0.5 (occupied and unknown) -> (tx*resolution + origin_x, ty*resolution +
+ * origin_y).  map: int8 [height*width]; wire_layout != 0: OccupancyGrid order data[y*width + x]
+ * (what the reference receives), else [x][y] (Mapping.pmap order).  Up to cap points are
+ * written (in arbitrary order); *count_out receives the number found. */
+int slam_map_obstacles(slam_ctx *ctx, const int8_t *map, int width, int height, int wire_layout, double resolution,
+                       double origin_x, double origin_y, double *ox, double *oy, int cap, int *count_out);
+int slam_map_obstacles_dev(slam_ctx *ctx, const int8_t *map, int width, int height, int wire_layout, double resolution,
+                           double origin_x, double origin_y, double *ox, double *oy, int cap, int *count_dev);
+
+/* Replaces Localization.laserEstimation(msg, x) (W9/localization.py:128-150) for B pose
+ * hypotheses: obstacle points (ox, oy)[K], poses [B][3] -> ranges_out [B][n] float64, the
+ * scan the map would produce (100.0 where no obstacle falls into a beam's bin). */
+int slam_virtual_scan(slam_ctx *ctx, const double *ox, const double *oy, int K, const double *poses, int B,
+                      double angle_min, double angle_increment, int n, double *ranges_out);
+int slam_virtual_scan_dev(slam_ctx *ctx, const double *ox, const double *oy, int K, const double *poses, int B,
+                          double angle_min, double angle_increment, int n, double *ranges_out);
+
+/* Replaces Localization.laserToNumpy (W9/localization.py:168-174) for float64 ranges (the
+ * virtual scan above is float64, not a float32 wire message): ranges [B][n] ->
+ * pts_out [B][2][n] float64. */
+int slam_scan_to_points_f64(slam_ctx *ctx, const double *ranges, const double *cos_t, const double *sin_t, int B, int n,
+                            double *pts_out);
+int slam_scan_to_points_f64_dev(slam_ctx *ctx, const double *ranges, const double *cos_t, const double *sin_t, int B,
+                                int n, double *pts_out);
+
+/* Replaces Localization.calc_map_observation(msg) (W9/localization.py:152-157) for B pose
+ * hypotheses: virtual scan of the map from poses[b] -> laserToNumpy (:168-174) -> ICP.process
+ * against the current scan's points src ([B][2][n] float64, or one shared [2][n] set when
+ * src_shared != 0).  cos_t, sin_t [n] as for slam_scan_to_points.  T_out [B][9];
+ * iters_out [B] nullable. */
+int slam_map_observation(slam_ctx *ctx, const double *ox, const double *oy, int K, const double *poses,
+                         const double *src, int B, int n, int src_shared, const double *cos_t, const double *sin_t,
+                         double angle_min, double angle_increment, int max_iter, double tol, double *T_out,
+                         int32_t *iters_out);
+/* Device form: needs workspaces vranges_ws [B][n] and vpts_ws [B][2][n] (float64). */
+int slam_map_observation_dev(slam_ctx *ctx, const double *ox, const double *oy, int K, const double *poses,
+                             const double *src, int B, int n, int src_shared, const double *cos_t,
+                             const double *sin_t, double angle_min, double angle_increment, int max_iter, double tol,
+                             double *vranges_ws, double *vpts_ws, double *T_out, int32_t *iters_out);
+
 #ifdef __cplusplus
 }
 #endif

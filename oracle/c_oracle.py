@@ -54,6 +54,9 @@ def lib():
         L.orc_occupancy_grid_data.argtypes = [C.c_void_p, _bp]
         L.orc_replay.argtypes = [_fp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_double, _dp, C.c_void_p, _dp, _dp, _ip, C.c_int]
         L.orc_replay.restype = C.c_long
+        L.orc_laser_estimation.argtypes = [_dp, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _dp]
+        L.orc_map_obstacles.argtypes = [_bp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_map_obstacles.restype = C.c_int
         L.orc_replay_mt.argtypes = L.orc_replay.argtypes
         L.orc_replay_mt.restype = C.c_long
         _LIB = L
@@ -177,3 +180,18 @@ def replay(ranges, angle_min, angle_max, grid=None, max_iter=30, tolerance=0.001
     if grid is not None:
         grid.visits += v
     return poses, T.reshape(-1, 3, 3), it, v
+
+
+def laser_estimation(obstacle, pose, angle_min, angle_increment, total_num):
+    """obstacle [2,K] -> virtual scan ranges [total_num] (float64)."""
+    out = np.empty(total_num)
+    lib().orc_laser_estimation(_c(obstacle[0]), _c(obstacle[1]), obstacle.shape[1], _c(pose), angle_min, angle_increment,
+                               total_num, out)
+    return out
+
+
+def map_obstacles(data, width, height, resolution, origin_x, origin_y):
+    d = _c(data, np.int8)
+    ox, oy = np.empty(width * height), np.empty(width * height)
+    k = lib().orc_map_obstacles(d, width, height, resolution, origin_x, origin_y, ox, oy)
+    return np.vstack((ox[:k], oy[:k]))

@@ -37,6 +37,7 @@ import numpy as np
 REF = "/root/reference"
 W12M = os.path.join(REF, "W12_LiDAR SLAM", "w12-mapping", "course_agv_slam", "scripts")
 W12F = os.path.join(REF, "W12_LiDAR SLAM", "w12-ekf-slam-final", "course_agv_slam", "scripts")
+W9 = os.path.join(REF, "W9_Fusion Localization (LiDAR Odometry)", "course_agv_slam", "scripts")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 syn = importlib.import_module("a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd.synthetic")
@@ -84,6 +85,7 @@ def _install_stubs():
         mod(pkg + ".msg", **{n: _Anything for n in names})
     mod("nav_msgs.srv", GetMap=_Anything)
     # out-of-scope collaborators of slam_ekf.py
+    mod("ekf", EKF=_Anything)                      # W9's 3-state EKF: out of scope
     mod("ekf_lm", EKF=_Anything, STATE_SIZE=3)
     mod("extraction", LandMarkSet=_Anything, Extraction=_Anything)
 
@@ -116,6 +118,7 @@ def load_reference():
     ref.icp_fhb = _load_asis("icp_fhb", os.path.join(W12F, "icp-fhb.py"))           # O3
     ref.icp = _load_py2("icp", os.path.join(W12M, "icp.py"))                        # O4
     ref.slam_ekf = _load_py2("slam_ekf", os.path.join(W12M, "slam_ekf.py"))
+    ref.localization = _load_py2("localization", os.path.join(W9, "localization.py"))   # imports the O4 `icp`
     return ref
 
 
@@ -380,14 +383,74 @@ def gen_g4(ref, out_dir):
     save(out_dir, "g4_pipeline.npz", **arrays)
 
 
+# ----------------------------------------------------------------------------
+# G5  scan-to-map observation (W9 localization.py updateMap / laserEstimation / calc_map_observation)
+# ----------------------------------------------------------------------------
+def gen_g5(ref, out_dir):
+    sys.modules["rospy"].get_param = lambda name, default=None: PARAMS.get(name, default)
+    Loc = ref.localization.Localization
+    arrays = {}
+    # a map: the final pmap of the G4 pipeline "a" in OccupancyGrid layout (unknown = 50 counts as obstacle, :56)
+    g4 = np.load(os.path.join(out_dir, "g4_pipeline.npz"))
+    data = g4["a_grid_data"]
+    class Info:  # nav_msgs/MapMetaData duck-type
+        pass
+    class Pos:
+        pass
+    msg = types.SimpleNamespace(data=data.tolist(), info=types.SimpleNamespace(
+        height=200, width=200, resolution=0.1, origin=types.SimpleNamespace(position=types.SimpleNamespace(x=-10.0, y=-10.0))))
+    node = object.__new__(Loc)
+    with quiet():
+        node.icp = ref.icp.ICP()
+    node.isFirstScan = True
+    node.laser_count = 0
+    with quiet():
+        node.updateMap(msg)
+    arrays["map_data"] = data
+    arrays["obstacle"] = node.obstacle
+    # virtual scans from several poses, 120 and 360 beams
+    rng = np.random.default_rng(55)
+    poses, vr120, vr360 = [], [], []
+    for k in range(6):
+        pose = [float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), float(rng.uniform(-np.pi, np.pi))]
+        node.xEst = pose
+        for n, store in ((120, vr120), (360, vr360)):
+            m = syn.LaserScan(ranges=tuple([1.0] * n), angle_min=syn.ANGLE_MIN, angle_max=syn.ANGLE_MAX,
+                              angle_increment=(syn.ANGLE_MAX - syn.ANGLE_MIN) / (n - 1))
+            est = node.laserEstimation(m, node.xEst)
+            store.append(np.array(est.ranges, dtype=np.float64))
+        poses.append(pose)
+    arrays.update(poses=np.array(poses), vscan120=np.array(vr120), vscan360=np.array(vr360))
+    # calc_map_observation: ICP of a real scan against the virtual scan of a small synthetic obstacle map
+    world = syn.World.room(1.0)
+    xs = np.arange(-5.0, 5.0001, 0.1)
+    ys = np.arange(-4.0, 4.0001, 0.1)
+    wall = np.concatenate([np.stack([xs, np.full_like(xs, -4.0)]), np.stack([xs, np.full_like(xs, 4.0)]),
+                           np.stack([np.full_like(ys, -5.0), ys]), np.stack([np.full_like(ys, 5.0), ys])], axis=1)
+    node.obstacle = wall
+    Ts, srcs, xests = [], [], []
+    for k in range(4):
+        true_pose = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(-np.pi, np.pi)])
+        guess = true_pose + np.array([rng.normal(0, 0.1), rng.normal(0, 0.1), rng.normal(0, 0.03)])
+        empty = syn.World(5.0, 4.0, (), 0.0)
+        r = syn.scans_from_poses(empty, true_pose[None], 120, 70 + k)[0]
+        m = syn.LaserScan(ranges=tuple(float(v) for v in r), angle_increment=(syn.ANGLE_MAX - syn.ANGLE_MIN) / 119)
+        node.xEst = [float(v) for v in guess]
+        node.src_pc = node.laserToNumpy(m)
+        T = node.calc_map_observation(m)
+        Ts.append(T), srcs.append(r), xests.append(guess)
+    arrays.update(obs_wall=wall, obs_T=np.array(Ts), obs_ranges=np.array(srcs), obs_xest=np.array(xests))
+    save(out_dir, "g5_map_observation.npz", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="g1,g2,g3,g4")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference()
-    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4)):
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5)):
         if name in args.only.split(","):
             t0 = time.time()
             fn(ref, args.out)

@@ -299,6 +299,45 @@ def occupancy_grid_data(pmap):
 
 
 # ----------------------------------------------------------------------------
+# f-1  scan-to-map observation (W9 = "W9_Fusion Localization (LiDAR Odometry)/course_agv_slam/scripts")
+# ----------------------------------------------------------------------------
+def map_obstacles(data, width, height, resolution, origin_x, origin_y):
+    """W9/localization.py:54-60 (updateMap): OccupancyGrid data (data[y*width + x]) ->
+    obstacle coordinates [2, K].  Cells > 20 or < -0.5 count, i.e. occupied AND unknown."""
+    map_data = np.array(data).reshape((-1, height)).transpose()
+    tx, ty = np.nonzero((map_data > 20) | (map_data < -0.5))
+    ox = (tx * resolution + origin_x) * 1.0
+    oy = (ty * resolution + origin_y) * 1.0
+    return np.vstack((ox, oy))
+
+
+def laser_estimation(obstacle, x_est, angle_min, angle_increment, total_num):
+    """W9/localization.py:128-150 (laserEstimation): the scan the map would produce from
+    pose x_est = (x, y, theta): every obstacle point drops its distance into the beam bin
+    int((atan2(dy, dx) - angle_min - theta) / angle_increment) (truncated, then wrapped into
+    [0, total_num)), bins keep the minimum, empty bins stay at 100.0."""
+    ranges = [100.0] * total_num
+    for i in range(obstacle.shape[1]):
+        dist = math.hypot(x_est[0] - obstacle[0][i], x_est[1] - obstacle[1][i])
+        index = int((math.atan2(obstacle[1][i] - x_est[1], obstacle[0][i] - x_est[0]) - angle_min - x_est[2]) / angle_increment)
+        while index > total_num - 1:
+            index = index - total_num
+        while index < 0:
+            index = index + total_num
+        if dist < ranges[index]:
+            ranges[index] = dist
+    return np.array(ranges)
+
+
+def map_observation(obstacle, x_est, src_pc, angle_min, angle_max, angle_increment, max_iter=30, tolerance=0.001):
+    """W9/localization.py:152-157 (calc_map_observation): ICP of the current scan against the
+    virtual scan of the map; laserToNumpy of :168-174 on the float64 virtual ranges."""
+    n = src_pc.shape[1]
+    tar_pc = laser_to_numpy(laser_estimation(obstacle, x_est, angle_min, angle_increment, n), angle_min, angle_max)
+    return icp_process(tar_pc, src_pc, max_iter, tolerance)
+
+
+# ----------------------------------------------------------------------------
 # pipeline (a-7 -> a-3 -> a-6 -> a-8 -> a-10), the unit bench.py counts as one scan
 # ----------------------------------------------------------------------------
 def replay(ranges, angle_min, angle_max, mapping, max_iter=30, tolerance=0.001,

@@ -419,3 +419,35 @@ long orc_replay_mt(const float *ranges, int n_scan, int n, const double *cos_t, 
     free(px); free(py);
     return visits;
 }
+
+/* f-1: W9 localization.py:128-150 (laserEstimation).  W9 = "W9_Fusion Localization (LiDAR
+ * Odometry)/course_agv_slam/scripts".  obstacle points (ox, oy)[K], pose (x, y, theta) ->
+ * ranges[total_num] (float64; 100.0 where no obstacle falls into the beam's bin). */
+void orc_laser_estimation(const double *ox, const double *oy, int K, const double pose[3], double angle_min,
+                          double angle_increment, int total_num, double *ranges)
+{
+    for (int i = 0; i < total_num; ++i) ranges[i] = 100.0;
+    for (int i = 0; i < K; ++i) {
+        double dist = hypot(pose[0] - ox[i], pose[1] - oy[i]);
+        double q = (atan2(oy[i] - pose[1], ox[i] - pose[0]) - angle_min - pose[2]) / angle_increment;
+        if (!(fabs(q) < 2.0e9)) continue;               /* NaN / huge: Python would raise or loop; skipped */
+        long index = (long)q;                             /* int(): truncation toward zero */
+        while (index > total_num - 1) index -= total_num;
+        while (index < 0) index += total_num;
+        if (dist < ranges[index]) ranges[index] = dist;
+    }
+}
+
+/* W9 localization.py:54-60 (updateMap): OccupancyGrid data[y*width + x] -> obstacle list, in
+ * numpy.nonzero order of map_data[x][y]; cells > 20 or < -0.5 (occupied and unknown). */
+int orc_map_obstacles(const int8_t *data, int width, int height, double resolution, double origin_x, double origin_y,
+                      double *ox, double *oy)
+{
+    int k = 0;
+    for (int x = 0; x < width; ++x)
+        for (int y = 0; y < height; ++y) {
+            int v = data[(size_t)y * width + x];
+            if (v > 20 || v < 0) { ox[k] = (x * resolution + origin_x) * 1.0; oy[k] = (y * resolution + origin_y) * 1.0; ++k; }
+        }
+    return k;
+}

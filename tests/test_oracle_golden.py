@@ -247,3 +247,39 @@ def test_c_replay_mt_equals_serial(syn):
     assert np.array_equal(p1, p2) and np.array_equal(i1, i2) and v1 == v2
     assert np.array_equal(g1_.pass_cnt, g2_.pass_cnt) and np.array_equal(g1_.hit_cnt, g2_.hit_cnt)
     assert np.array_equal(g1_.pmap, g2_.pmap)
+
+
+# ---------------------------------------------------------------- G5 scan-to-map observation
+@pytest.fixture(scope="module")
+def g5():
+    from conftest import load_golden
+    return load_golden("g5_map_observation.npz")
+
+
+@pytest.mark.parametrize("impl", ["np", "c"])
+def test_map_obstacles(g5, impl):
+    f = on.map_obstacles if impl == "np" else co.map_obstacles
+    obs = f(g5["map_data"], 200, 200, 0.1, -10.0, -10.0)
+    assert obs.shape == g5["obstacle"].shape and np.array_equal(obs, g5["obstacle"])
+    assert int(np.sum(g5["map_data"] == 50)) > 0           # unknown cells count as obstacles (> 20)
+
+
+@pytest.mark.parametrize("impl", ["np", "c"])
+def test_laser_estimation(g5, impl):
+    f = on.laser_estimation if impl == "np" else co.laser_estimation
+    for n, key in ((120, "vscan120"), (360, "vscan360")):
+        inc = (3.14159 - -3.14159) / (n - 1)
+        for k in range(g5["poses"].shape[0]):
+            got = f(g5["obstacle"], g5["poses"][k], -3.14159, inc, n)
+            if impl == "np":
+                assert np.array_equal(got, g5[key][k]), (n, k)    # same math.hypot / atan2: bit-exact
+            else:   # C hypot() and CPython's math.hypot may differ in the last bit; the bins may not
+                assert np.max(np.abs(got - g5[key][k])) < 1e-12 and np.array_equal(got == 100.0, g5[key][k] == 100.0)
+
+
+def test_map_observation(g5):
+    inc = (3.14159 - -3.14159) / 119
+    for k in range(g5["obs_T"].shape[0]):
+        src = on.laser_to_numpy(g5["obs_ranges"][k], -3.14159, 3.14159)
+        T = on.map_observation(g5["obs_wall"], g5["obs_xest"][k], src, -3.14159, 3.14159, inc)
+        assert np.max(np.abs(T - g5["obs_T"][k])) < FTOL
