@@ -73,6 +73,8 @@ _SIGS = {
     "slam_replay": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "slam_particles": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp], _i),
     "slam_particles_dev": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp], _i),
+    "slam_grid_update_scans": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
+    "slam_grid_update_scans_dev": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "slam_map_obstacles": ([_vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _i, C.POINTER(_i)], _i),
     "slam_map_obstacles_dev": ([_vp, _vp, _i, _i, _i, _d, _d, _d, _vp, _vp, _i, _vp], _i),
     "slam_virtual_scan": ([_vp, _vp, _vp, _i, _vp, _i, _d, _d, _i, _vp], _i),

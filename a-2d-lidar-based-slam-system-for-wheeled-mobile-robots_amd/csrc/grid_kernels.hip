@@ -249,6 +249,8 @@ struct ReplaySource {
     int n_scan, n;
     long traj_stride;      // floats between trajectories' scan blocks (0: every trajectory reads the same scans)
     int grid_per_traj;     // trajectory l casts into map l (particle hypotheses, BASELINE configs[2])
+    const double *centres; // nullable [L][n_scan-1][2]: ray origins that are not the pose (w12-mapping-online,
+                           // W12o/slam_ekf.py:71-77,104: the centre comes from /tf, the points from xEst)
     __device__ int scans_per_traj() const { return n_scan - 1; }
     __device__ int own_grid(int l) const { return grid_per_traj ? l : 0; }
     __device__ void scan_const(int l, int k, const GridDev &g, ScanConst &sc) const
@@ -257,8 +259,13 @@ struct ReplaySource {
         sc.px = pose[0]; sc.py = pose[1];
         sc.c = cos(pose[2]); sc.s = sin(pose[2]);
         sc.cbad = 0;
-        sc.pcx = to_cell(sc.px, g.scale, g.off_x, sc.cbad);
-        sc.pcy = to_cell(sc.py, g.scale, g.off_y, sc.cbad);
+        double ox = sc.px, oy = sc.py;
+        if (centres) {
+            const double *ctr = centres + 2 * ((size_t)l * (n_scan - 1) + k);
+            ox = ctr[0]; oy = ctr[1];
+        }
+        sc.pcx = to_cell(ox, g.scale, g.off_x, sc.cbad);
+        sc.pcy = to_cell(oy, g.scale, g.off_y, sc.cbad);
     }
     // false: beam skipped (mapping.py:30) or flagged in `bad`
     __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
@@ -534,36 +541,49 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
         if (shared_scans || grid_per_traj) return hipErrorInvalidValue;   // n too large for the window kernel
         return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
     }
-    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj};
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj, nullptr};
     return launch_win(g, src, L, n_scan - 1, n, G, got, s);
 }
 
+// S scans cast from given poses, optionally with ray origins of their own.
+hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s)
+{
+    int G = pick_group(group, S, S, n);
+    if (G == 0) return hipErrorInvalidValue;                          // n too large for the window kernel
+    // the replay source reads scan k+1 of a stream of n_scan = S+1: shift the base by one scan
+    ReplaySource src{ranges - n, cos_t, sin_t, poses, S + 1, n, 0L, 0, centres};
+    return launch_win(g, src, 1, S, n, G, nullptr, s);
+}
+
 // mapping.py:47-50 applied to the integer counters (see the header comment).
+struct OccRule {
+    int hit_levels;
+    uint32_t pass_thresh[kMaxHitLevels];
+    __device__ __forceinline__ uint32_t value(uint32_t p, uint32_t h) const
+    {
+        if ((p | h) == 0) return 50u;
+        if (h >= (uint32_t)hit_levels) return 100u;
+        uint32_t t = pass_thresh[0];
+#pragma unroll
+        for (int k = 1; k < kMaxHitLevels; ++k) t = (h == (uint32_t)k) ? pass_thresh[k] : t;
+        return p >= t ? 100u : 0u;
+    }
+};
+
 __global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,
-                                                       size_t cells, uint32_t pass_thresh, int hit_occupies,
-                                                       int8_t *__restrict__ pmap)
+                                                       size_t cells, OccRule rule, int8_t *__restrict__ pmap)
 {
     size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; c < cells; c += stride) {
         if (c + 4 <= cells) {
             uint4 p = *reinterpret_cast<const uint4 *>(pass + c);
             uint4 h = *reinterpret_cast<const uint4 *>(hit + c);
-            const uint32_t pp[4] = {p.x, p.y, p.z, p.w}, hh[4] = {h.x, h.y, h.z, h.w};
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                bool touched = (pp[k] | hh[k]) != 0;
-                bool occ = (hit_occupies && hh[k] >= 1) || pp[k] >= pass_thresh;
-                uint32_t v = touched ? (occ ? 100u : 0u) : 50u;
-                out |= v << (8 * k);
-            }
+            uint32_t out = rule.value(p.x, h.x) | rule.value(p.y, h.y) << 8 | rule.value(p.z, h.z) << 16 |
+                           rule.value(p.w, h.w) << 24;
             *reinterpret_cast<uint32_t *>(pmap + c) = out;
         } else {
-            for (size_t e = c; e < cells; ++e) {
-                bool touched = (pass[e] | hit[e]) != 0;
-                bool occ = (hit_occupies && hit[e] >= 1) || pass[e] >= pass_thresh;
-                pmap[e] = touched ? (occ ? 100 : 0) : 50;
-            }
+            for (size_t e = c; e < cells; ++e) pmap[e] = (int8_t)rule.value(pass[e], hit[e]);
         }
     }
 }
@@ -574,8 +594,10 @@ hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pm
     size_t blocks = (cells / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells,
-                       g.pass_thresh, g.hit_occupies, pmap);
+    OccRule rule;
+    rule.hit_levels = g.hit_levels;
+    for (int k = 0; k < kMaxHitLevels; ++k) rule.pass_thresh[k] = g.pass_thresh[k];
+    hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells, rule, pmap);
     return hipGetLastError();
 }
 

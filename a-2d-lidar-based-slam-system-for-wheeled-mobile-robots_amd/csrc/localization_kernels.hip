@@ -12,7 +12,7 @@
 // The projection is a scatter-min: every obstacle drops its distance into one beam bin and
 // the bin keeps the smallest.  Distances are non-negative float64, whose bit patterns order
 // like the values, so the minimum is an integer atomicMin on the bits: order-free and
-// reproducible.  One lane per (obstacle, pose hypothesis).
+// reproducible.  One lane per (obstacle, pose hypothesis), bins privatised in LDS.
 #include <hip/hip_runtime.h>
 
 #include "slam_internal.h"
@@ -49,23 +49,39 @@ __global__ void __launch_bounds__(256) k_fill_u64(unsigned long long *p, long n,
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// laserEstimation (localization.py:128-150).  blockIdx.y = pose hypothesis.
+// laserEstimation (localization.py:128-150).  blockIdx.y = pose hypothesis, blockIdx.x = slice
+// of the obstacle list.  The beam bins of the hypothesis live in LDS (n x 8 B) and take the
+// scatter-min there (ds_min_u64); a workgroup that owns the whole list stores its bins,
+// otherwise the slices meet in global memory with one atomicMin per touched bin.
 __global__ void __launch_bounds__(256) k_virtual_scan(const double *__restrict__ ox, const double *__restrict__ oy, int K,
                                                       const double *__restrict__ poses, double angle_min,
-                                                      double angle_increment, int n, unsigned long long *__restrict__ ranges)
+                                                      double angle_increment, int n, unsigned long long empty,
+                                                      unsigned long long *__restrict__ ranges)
 {
+    extern __shared__ unsigned long long bins[];
     const int b = blockIdx.y;
     const double px = poses[3 * b], py = poses[3 * b + 1], pth = poses[3 * b + 2];
     unsigned long long *r = ranges + (long)b * n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
-        double dx = ox[i] - px, dy = oy[i] - py;
-        double dist = hypot(px - ox[i], py - oy[i]);                                  // :138
-        double q = (atan2(dy, dx) - angle_min - pth) / angle_increment;               // :139
+    for (int i = threadIdx.x; i < n; i += blockDim.x) bins[i] = empty;
+    __syncthreads();
+    const int per = (K + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(K, lo + per);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double x = ox[i], y = oy[i];
+        double dist = hypot(px - x, py - y);                                          // :138
+        double q = (atan2(y - py, x - px) - angle_min - pth) / angle_increment;       // :139
         if (!(fabs(q) < 2.0e9)) continue;                // NaN / absurd: the reference would raise or spin
         long index = (long)q;                            // int(): truncation toward zero
         index %= n;                                      // the two while-loops of :141-144
         if (index < 0) index += n;
-        atomicMin(&r[index], (unsigned long long)__double_as_longlong(dist));         // :145-146 (strict '<' = min)
+        atomicMin(&bins[index], (unsigned long long)__double_as_longlong(dist));      // :145-146 (strict '<' = min)
+    }
+    __syncthreads();
+    if (gridDim.x == 1) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) r[i] = bins[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (bins[i] < empty) atomicMin(&r[i], bins[i]);
     }
 }
 
@@ -102,15 +118,17 @@ hipError_t launch_virtual_scan(const double *ox, const double *oy, int K, const 
     const double hundred = 100.0;                                    // data.ranges = [100.0]*total_num (:135)
     unsigned long long bits;
     memcpy(&bits, &hundred, sizeof bits);
+    // enough workgroups to fill 256 CUs a few times over; a slice is at least 1024 obstacles
+    int slices = (2048 + B - 1) / B;
+    int max_slices = (K + 1023) / 1024;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
     long total = (long)B * n;
-    hipLaunchKernelGGL(k_fill_u64, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<unsigned long long *>(ranges), total, bits);
-    if (K > 0) {
-        int bx = (K + 255) / 256;
-        if (bx > 1024) bx = 1024;
-        hipLaunchKernelGGL(k_virtual_scan, dim3(bx, B), dim3(256), 0, s, ox, oy, K, poses, angle_min, angle_increment, n,
-                           reinterpret_cast<unsigned long long *>(ranges));
-    }
+    if (slices > 1)
+        hipLaunchKernelGGL(k_fill_u64, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<unsigned long long *>(ranges), total, bits);
+    hipLaunchKernelGGL(k_virtual_scan, dim3(slices, B), dim3(256), (size_t)n * 8, s, ox, oy, K, poses, angle_min,
+                       angle_increment, n, bits, reinterpret_cast<unsigned long long *>(ranges));
     return hipGetLastError();
 }
 

@@ -486,23 +486,35 @@ int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double of
     REQUIRE(G > 0 && xw > 0 && yw > 0, "G, xw, yw must be positive");
     REQUIRE(scale > 0 && std::isfinite(scale) && std::isfinite(off_x) && std::isfinite(off_y), "bad index rule");
     REQUIRE(free_inc > 0 && hit_inc > 0 && std::isfinite(thresh), "increments must be positive");
-    REQUIRE(hit_inc > thresh,
-            "hit_inc <= thresh makes the occupied test depend on the order of float additions (the +4 variant of "
-            "w12-mapping-online); not supported");
+    // Occupied rule on the integer counters.  The reference keeps a float64 running sum per
+    // cell (mapping.py:43,45) and tests it against thresh (:47).  With h hits and p passes the
+    // sum is evaluated here in ONE canonical order, hits first, with the same sequential IEEE
+    // adds: hit_levels = fewest hits that exceed thresh on their own (1 for +20; 3 for the +4
+    // of w12-mapping-online), pass_thresh[h] = fewest passes that exceed it after h hits
+    // (1001 for (0.01, 10), because 1000 sequential adds of 0.01 give 9.99999999999983).
+    // For +20 the rule is exactly the reference's in any order.  For +4 the reference's own
+    // answer depends on the order in which a cell's +4 and +0.01 arrived when p is exactly on
+    // a threshold (p = pass_thresh[h] - 1 or pass_thresh[h]; the rounding of <= 1001 adds is
+    // ~1e-13 << 0.01, so no other p is affected): those cells follow the canonical order.
+    uint32_t levels = 0, table[kMaxHitLevels];
+    {
+        volatile double base = 0.0;
+        while (levels < (uint32_t)kMaxHitLevels && !(base > thresh)) {
+            volatile double acc = base;
+            uint32_t k = 0;
+            while (!(acc > thresh) && k < 0xfffffff0u) { acc = acc + free_inc; ++k; }
+            table[levels++] = k;
+            base = base + hit_inc;
+        }
+        REQUIRE(base > thresh, "hit_inc is too small: more than 8 hits would be needed to exceed thresh");
+    }
     slam_grid *g = new slam_grid();
     size_t cells = (size_t)G * xw * yw;
     g->d.G = G; g->d.xw = xw; g->d.yw = yw;
     g->d.scale = scale; g->d.off_x = off_x; g->d.off_y = off_y;
     g->d.free_inc = free_inc; g->d.hit_inc = hit_inc;
-    g->d.hit_occupies = hit_inc > thresh;
-    // Smallest k whose float64 running sum of k additions of free_inc exceeds thresh
-    // (mapping.py:43,47): 1001 for (0.01, 10).  Evaluated with the same sequential IEEE adds.
-    {
-        volatile double acc = 0.0;
-        uint32_t k = 0;
-        while (!(acc > thresh) && k < 0xfffffff0u) { acc = acc + free_inc; ++k; }
-        g->d.pass_thresh = k;
-    }
+    g->d.hit_levels = (int)levels;
+    for (uint32_t k = 0; k < (uint32_t)kMaxHitLevels; ++k) g->d.pass_thresh[k] = k < levels ? table[k] : 0;
     g->d.status = c->status;
     // one allocation [pass | hit | visit counter] so that a reset is a single memset
     g->state_bytes = align_up(cells * 4) * 2 + 256;
@@ -577,6 +589,39 @@ int slam_grid_update(slam_ctx *c, slam_grid *g, const double *ox, const double *
     H2D(d_cy, cy, (size_t)B * 8);
     if (grid_of_batch) H2D(d_g, grid_of_batch, (size_t)B * 4);
     TRY(slam_grid_update_dev(c, g, d_x, d_y, d_cx, d_cy, B, n, d_g));
+    return check_status_sync(c);
+}
+
+int slam_grid_update_scans_dev(slam_ctx *c, slam_grid *g, const float *ranges, const double *cos_t, const double *sin_t,
+                               const double *poses, const double *centres, int S, int n)
+{
+    TRY(use(c));
+    REQUIRE(g && ranges && cos_t && sin_t && poses, "null pointer");
+    REQUIRE(S > 0 && n > 0 && n <= 65535, "bad sizes");
+    Timed t(c, SLAM_K_GRID);
+    HIPCHK(launch_grid_update_scans(g->d, ranges, cos_t, sin_t, poses, centres, S, n, c->grid_group, c->stream));
+    return SLAM_OK;
+}
+
+int slam_grid_update_scans(slam_ctx *c, slam_grid *g, const float *ranges, const double *cos_t, const double *sin_t,
+                           const double *poses, const double *centres, int S, int n)
+{
+    TRY(use(c));
+    REQUIRE(g && ranges && cos_t && sin_t && poses, "null pointer");
+    REQUIRE(S > 0 && n > 0 && n <= 65535, "bad sizes");
+    size_t nr = (size_t)S * n;
+    TRY(arena_reserve(c, c->staging, align_up(nr * 4) + 2 * align_up((size_t)n * 8) + align_up((size_t)S * 24) +
+                                         align_up((size_t)S * 16) + 2048));
+    float *d_r = carve<float>(c->staging, nr);
+    double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
+    double *d_p = carve<double>(c->staging, (size_t)S * 3);
+    double *d_o = centres ? carve<double>(c->staging, (size_t)S * 2) : nullptr;
+    H2D(d_r, ranges, nr * 4);
+    H2D(d_c, cos_t, (size_t)n * 8);
+    H2D(d_s, sin_t, (size_t)n * 8);
+    H2D(d_p, poses, (size_t)S * 24);
+    if (centres) H2D(d_o, centres, (size_t)S * 16);
+    TRY(slam_grid_update_scans_dev(c, g, d_r, d_c, d_s, d_p, d_o, S, n));
     return check_status_sync(c);
 }
 
@@ -869,7 +914,7 @@ int slam_virtual_scan_dev(slam_ctx *c, const double *ox, const double *oy, int K
 {
     TRY(use(c));
     REQUIRE((K == 0 || (ox && oy)) && poses && ranges_out, "null pointer");
-    REQUIRE(K >= 0 && B > 0 && n > 0 && B <= 65535, "bad sizes");
+    REQUIRE(K >= 0 && B > 0 && n > 0 && n <= 8192 && B <= 65535, "bad sizes");
     REQUIRE(angle_increment != 0.0 && std::isfinite(angle_increment) && std::isfinite(angle_min), "bad angles");
     HIPCHK(launch_virtual_scan(ox, oy, K, poses, B, angle_min, angle_increment, n, ranges_out, c->stream));
     return SLAM_OK;

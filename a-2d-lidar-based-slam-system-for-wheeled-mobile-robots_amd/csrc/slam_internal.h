@@ -47,14 +47,18 @@ hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int 
                                const double *prior = nullptr);
 
 // ---- grid --------------------------------------------------------------------------
+constexpr int kMaxHitLevels = 8;
+
 struct GridDev {
     int G, xw, yw;
     double scale, off_x, off_y;
     uint32_t *pass, *hit;          // [G][xw][yw]
     unsigned long long *visits;    // in-bounds cell visits since reset
     int *status;                   // sticky kStatus* bits (context-wide)
-    uint32_t pass_thresh;          // smallest pass count whose float64 running sum exceeds thresh
-    int hit_occupies;              // hit_inc > thresh: one hit marks the cell occupied
+    // Occupied rule on the integer counters (see slam_grid_create): a cell with h hits and p
+    // passes is occupied iff h >= hit_levels or p >= pass_thresh[h].
+    int hit_levels;                // 1 for the reference's +20 (one hit occupies), 3 for the online variant's +4
+    uint32_t pass_thresh[kMaxHitLevels];
     double free_inc, hit_inc;
 };
 
@@ -73,6 +77,8 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
                                          const double *sin_t, const double *poses, int L, int n_scan, int n,
                                          const int32_t *grid_of_traj, int group, hipStream_t s, int shared_scans = 0,
                                          int grid_per_traj = 0);
+hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
 hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);

@@ -13,6 +13,11 @@ Fidelity notes:
   (or use :meth:`Mapping.metric`) for grids of another resolution such as 400x400 @ 0.05 m.
 * ``datamap`` is rebuilt as ``0.01*pass + 20*hit`` from the counters; it equals the
   reference's running float sum to ~1e-12, ``pmap`` is exact.
+* ``hit_inc=4`` gives the w12-mapping-online variant (W12o/mapping.py:46).  There the
+  reference's own ``pmap`` depends on the order in which a cell's +4 and +0.01 arrived when
+  the pass count sits exactly on a threshold (e.g. 2 hits + 200 passes: 8 + 200 x 0.01 is
+  occupied if the passes came first, free if the hits did); the device applies the
+  hits-first order (include/slam_hip.h, slam_grid_create).
 * NaN coordinates raise ``ValueError`` and infinite ``oy`` / centre raise ``OverflowError``
   as ``int()`` does in the reference.  The reference stops at the offending beam (earlier
   beams are already in the map); here every other beam of the call is applied.  A cell index
@@ -81,6 +86,26 @@ class Mapping:
         L = _abi.lib()
         _abi.check(L.slam_grid_update(self._ctx.handle, self._grid, _abi.ptr(ox), _abi.ptr(oy), _abi.ptr(cx),
                                       _abi.ptr(cy), 1, n, None))
+        _abi.check(L.slam_grid_read(self._ctx.handle, self._grid, 0, _abi.ptr(self._p8), _abi.ptr(self.datamap),
+                                    None, None))
+        self.pmap[...] = self._p8
+        return self.pmap
+
+    def update_scans(self, ranges, angle_min, angle_max, poses, centres=None):
+        """S raw scans at once (``slam_grid_update_scans``): ranges [S, n] (inf -> 30 m), poses
+        [S, 3] the xEst each scan is transformed with (W12m/slam_ekf.py:89), centres [S, 2] the
+        ray origins (default: the pose; w12-mapping-online passes the /tf position,
+        W12o/slam_ekf.py:104).  Returns the live ``pmap``."""
+        r = np.ascontiguousarray(np.asarray(ranges, dtype=np.float32))
+        if r.ndim == 1:
+            r = r[None]
+        S, n = r.shape
+        p = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(S, 3))
+        c = None if centres is None else np.ascontiguousarray(np.asarray(centres, dtype=np.float64).reshape(S, 2))
+        ct, st = _abi.trig_tables(angle_min, angle_max, n)
+        L = _abi.lib()
+        _abi.check(L.slam_grid_update_scans(self._ctx.handle, self._grid, _abi.ptr(r), _abi.ptr(ct), _abi.ptr(st),
+                                            _abi.ptr(p), _abi.ptr(c), S, n))
         _abi.check(L.slam_grid_read(self._ctx.handle, self._grid, 0, _abi.ptr(self._p8), _abi.ptr(self.datamap),
                                     None, None))
         self.pmap[...] = self._p8

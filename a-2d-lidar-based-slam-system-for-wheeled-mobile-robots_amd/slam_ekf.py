@@ -31,8 +31,15 @@ STATE_SIZE = 3
 
 
 class SLAM_EKF:  # noqa: N801 (the reference's class name)
-    def __init__(self, context=None):
+    def __init__(self, context=None, online=False):
+        """``online=True`` is the node of w12-mapping-online: +4 end-point evidence
+        (W12o/mapping.py:46), every 6th message (W12o/slam_ekf.py:81) and ray origins taken
+        from the last /tf message (``tf_callback``, :71-77,104) instead of xEst."""
         self._ctx = context or _abi.default_context()
+        self.online = bool(online)
+        self.x_online = 0
+        self.y_online = 0
+        self.z_online = 0
         self.robot_x = get_param('/slam/robot_x', 0)
         self.robot_y = get_param('/slam/robot_y', 0)
         self.robot_theta = get_param('/slam/robot_theta', 0)
@@ -43,7 +50,8 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
         self.map_reso = get_param('/slam/map_resolution', 0.1)
         self.map_cellx_width = int(round(self.map_x_width / self.map_reso))
         self.map_celly_width = int(round(self.map_y_width / self.map_reso))
-        self.mapping = Mapping(self.map_cellx_width, self.map_celly_width, self.map_reso, context=self._ctx)
+        self.mapping = Mapping(self.map_cellx_width, self.map_celly_width, self.map_reso, context=self._ctx,
+                               hit_inc=4.0 if self.online else 20.0)
         self.icp = ICP(context=self._ctx)
         self.sensor_sta = [self.robot_x, self.robot_y, self.robot_theta]
         self.isFirstScan = True
@@ -74,9 +82,16 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
         m.ranges, (m.angle_min, m.angle_max) = ranges, self._angles
         return scan_to_pc(m, clip_inf=True, context=self._ctx)
 
+    def tf_callback(self, msg):
+        """W12o/slam_ekf.py:71-77: remember the translation of the last transform."""
+        for i in msg.transforms:
+            self.x_online = i.transform.translation.x
+            self.y_online = i.transform.translation.y
+            self.z_online = i.transform.translation.z
+
     def laserCallback(self, msg):
         self.laser_count += 1
-        if self.laser_count < 5:                                   # :65-67
+        if self.laser_count < (6 if self.online else 5):           # :65-67 / W12o :81
             return
         self.laser_count = 0
         ranges = np.ascontiguousarray(np.asarray(msg.ranges, dtype=np.float32))
@@ -96,7 +111,13 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
         tol = get_param('/icp/tolerance', 0.001)                   # icp.py:40
         _abi.check(_abi.lib().slam_replay(self._ctx.handle, _abi.ptr(pair), _abi.ptr(ct), _abi.ptr(st), 1, 2, n,
                                           _abi.F64, int(self.icp.max_iter), float(tol), _abi.ptr(pose0),
-                                          self.mapping._grid, None, _abi.ptr(pose), _abi.ptr(T), _abi.ptr(it)))
+                                          None if self.online else self.mapping._grid, None, _abi.ptr(pose),
+                                          _abi.ptr(T), _abi.ptr(it)))
+        if self.online:                                            # W12o :102-104
+            centre = np.array([[float(self.x_online), float(self.y_online)]])
+            _abi.check(_abi.lib().slam_grid_update_scans(self._ctx.handle, self.mapping._grid, _abi.ptr(ranges),
+                                                         _abi.ptr(ct), _abi.ptr(st), _abi.ptr(pose), _abi.ptr(centre),
+                                                         1, n))
         self._prev_ranges = ranges                                 # calc_odometry :112
         self._tar_cloud = None
         self.last_T = T.reshape(3, 3)

@@ -128,7 +128,13 @@ int slam_pose_compose_dev(slam_ctx *ctx, const double *T, const double *pose0, i
 /* Replaces Mapping.__init__(xw, yw, xyreso) (W12m/mapping.py:8-20) for G independent
  * maps.  Cell index rule: int(scale * (x + off)) truncated toward zero; the reference
  * hard-codes scale = off_x = off_y = 10 (:33-36).  free_inc / hit_inc / thresh are the
- * +0.01 / +20 / >10 of :43-47.  Evidence is held as integer pass / hit counters. */
+ * +0.01 / +20 / >10 of :43-47 (hit_inc = 4 gives the w12-mapping-online variant,
+ * W12o/mapping.py:46).  Evidence is held as integer pass / hit counters; a cell with h hits
+ * and p passes is occupied iff the float64 running sum "h x hit_inc, then p x free_inc"
+ * (sequential IEEE adds, hits first) exceeds thresh.  For hit_inc > thresh that is the
+ * reference's answer whatever the order of arrival; for the +4 variant the reference's own
+ * answer is order-dependent when p sits exactly on a threshold, and this canonical order
+ * decides.  At most 8 hits may be needed to exceed thresh (else SLAM_ERR_INVALID). */
 int slam_grid_create(slam_ctx *ctx, int G, int xw, int yw, double scale, double off_x, double off_y,
                      double free_inc, double hit_inc, double thresh, slam_grid **out);
 int slam_grid_destroy(slam_ctx *ctx, slam_grid *grid);
@@ -141,6 +147,17 @@ int slam_grid_update(slam_ctx *ctx, slam_grid *grid, const double *ox, const dou
                      const double *cy, int B, int n, const int32_t *grid_of_batch);
 int slam_grid_update_dev(slam_ctx *ctx, slam_grid *grid, const double *ox, const double *oy,
                          const double *cx, const double *cy, int B, int n, const int32_t *grid_of_batch);
+
+/* Replaces the map-building lines of SLAM_EKF.laserCallback for S scans at once:
+ * obs = u2T(xEst).dot(laserToNumpy(msg)) (inf -> 30 m) and mapping.update(obs[0], obs[1],
+ * centre) (W12m/slam_ekf.py:88-90, :115-123).  ranges float32 [S][n]; poses [S][3] = xEst of
+ * each scan; centres [S][2] = the ray origins, or NULL to cast from the pose as w12-mapping
+ * does.  w12-mapping-online takes the centre from /tf instead (W12o/slam_ekf.py:71-77,104).
+ * All S scans go into map 0. */
+int slam_grid_update_scans(slam_ctx *ctx, slam_grid *grid, const float *ranges, const double *cos_t,
+                           const double *sin_t, const double *poses, const double *centres, int S, int n);
+int slam_grid_update_scans_dev(slam_ctx *ctx, slam_grid *grid, const float *ranges, const double *cos_t,
+                               const double *sin_t, const double *poses, const double *centres, int S, int n);
 
 /* Read map g back (what Mapping.update returns, mapping.py:51, plus the state behind it).
  * Any output may be NULL.  pmap [xw][yw] int8 in {0, 50, 100}; datamap [xw][yw] float64

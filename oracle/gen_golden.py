@@ -37,6 +37,7 @@ import numpy as np
 REF = "/root/reference"
 W12M = os.path.join(REF, "W12_LiDAR SLAM", "w12-mapping", "course_agv_slam", "scripts")
 W12F = os.path.join(REF, "W12_LiDAR SLAM", "w12-ekf-slam-final", "course_agv_slam", "scripts")
+W12O = os.path.join(REF, "W12_LiDAR SLAM", "w12-mapping-online", "course_agv_slam", "scripts")
 W9 = os.path.join(REF, "W9_Fusion Localization (LiDAR Odometry)", "course_agv_slam", "scripts")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -118,6 +119,7 @@ def load_reference():
     ref.icp_fhb = _load_asis("icp_fhb", os.path.join(W12F, "icp-fhb.py"))           # O3
     ref.icp = _load_py2("icp", os.path.join(W12M, "icp.py"))                        # O4
     ref.slam_ekf = _load_py2("slam_ekf", os.path.join(W12M, "slam_ekf.py"))
+    ref.mapping_online = _load_asis("mapping_online", os.path.join(W12O, "mapping.py"))   # O2, the +4 variant
     ref.localization = _load_py2("localization", os.path.join(W9, "localization.py"))   # imports the O4 `icp`
     return ref
 
@@ -443,14 +445,76 @@ def gen_g5(ref, out_dir):
     save(out_dir, "g5_map_observation.npz", **arrays)
 
 
+def gen_g6(ref, out_dir):
+    """w12-mapping-online: Mapping with the +4 end-point increment
+    (W12o/mapping.py:46) and ray origins that are NOT the pose the points were transformed
+    with (W12o/slam_ekf.py:71-77,104: the centre comes from /tf)."""
+    arrays = {}
+    rng = np.random.default_rng(66)
+    world = syn.World.room(1.0)
+    n, S = 120, 60
+    # a robot creeping 2 mm per scan: cells are revisited often enough for every level of the
+    # rule to occur (0, 1, 2, >= 3 hits with passes below / above the thresholds)
+    poses = np.stack([0.5 + 0.002 * np.arange(S), -0.3 + 0.001 * np.arange(S), 0.2 + 0.003 * np.arange(S)], axis=1)
+    ranges = syn.scans_from_poses(world, poses, n, 61, noise=0.03)
+    centres = poses[:, :2] + rng.normal(0, 0.02, size=(S, 2))       # what /tf said, not what xEst says
+    ang = np.linspace(syn.ANGLE_MIN, syn.ANGLE_MAX, n)
+    m = ref.mapping_online.Mapping(200, 200, 0.1)
+    ox_all, oy_all, snaps = [], [], []
+    for k in range(S):
+        r = ranges[k].astype(np.float64)
+        lx, ly = np.cos(ang) * r, np.sin(ang) * r
+        c, s_ = np.cos(poses[k, 2]), np.sin(poses[k, 2])
+        ox = c * lx - s_ * ly + poses[k, 0]
+        oy = s_ * lx + c * ly + poses[k, 1]
+        pmap = m.update(ox, oy, centres[k, 0], centres[k, 1])
+        ox_all.append(ox), oy_all.append(oy)
+        if k in (9, 29, S - 1):
+            snaps.append(np.array(pmap, dtype=np.int8))
+    arrays.update(ox=np.array(ox_all), oy=np.array(oy_all), centres=centres, snap_steps=np.array([9, 29, S - 1]),
+                  pmap_snaps=np.array(snaps), datamap=np.array(m.datamap))
+    # stress: a standing robot, three bursts of short beams (hits 0.35 / 0.55 m away) between
+    # 147 scans of long beams through the same cells, so that cells with exactly 1 and 2 hits
+    # cross the threshold by pass count (4 + 601 x 0.01, 8 + 201 x 0.01)
+    cx, cy = 0.03, 0.04
+    m = ref.mapping_online.Mapping(200, 200, 0.1)
+    sx, sy, slen = [], [], []
+    for k in range(150):
+        if k in (0, 50, 100):
+            a = rng.uniform(-np.pi, np.pi, size=32)
+            r = np.concatenate([np.full(16, 0.35), np.full(16, 0.55)])
+        else:
+            a = np.linspace(-np.pi, np.pi, 120, endpoint=False) + rng.uniform(0, 2 * np.pi)
+            r = np.full(120, 6.0) + rng.normal(0, 0.05, 120)
+        ox, oy = cx + r * np.cos(a), cy + r * np.sin(a)
+        pmap = m.update(ox, oy, cx, cy)
+        sx.append(ox), sy.append(oy), slen.append(len(ox))
+    arrays.update(stress_ox=np.concatenate(sx), stress_oy=np.concatenate(sy), stress_len=np.array(slen),
+                  stress_centre=np.array([cx, cy]), stress_pmap=np.array(pmap, dtype=np.int8),
+                  stress_datamap=np.array(m.datamap))
+    # boundary: one cell X = (130, 100) with h hits and p passes arriving in two different
+    # orders; the reference's own answer depends on the order when p sits on the threshold
+    far, at = ([5.05], [0.05]), ([3.05], [0.05])          # a beam through X, a beam ending in X
+    cases = []
+    for h, p in ((1, 600), (1, 601), (2, 200), (2, 201)):
+        for order in ("hits_first", "passes_first"):
+            mm = ref.mapping_online.Mapping(200, 200, 0.1)
+            seq = [at] * h + [far] * p if order == "hits_first" else [far] * p + [at] * h
+            for ox, oy in seq:
+                mm.update(np.array(ox), np.array(oy), 0.05, 0.05)
+            cases.append((h, p, order == "hits_first", mm.pmap[130][100], mm.datamap[130][100]))
+    arrays.update(boundary_cases=np.array(cases, dtype=np.float64), boundary_cell=np.array([130, 100]))
+    save(out_dir, "g6_mapping_online.npz", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference()
-    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5)):
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6)):
         if name in args.only.split(","):
             t0 = time.time()
             fn(ref, args.out)

@@ -231,15 +231,28 @@ def bresenham_path(start, end):
 # ----------------------------------------------------------------------------
 # a-9 / a-10  Mapping
 # ----------------------------------------------------------------------------
-def pass_count_threshold(free_inc=0.01, thresh=10.0):
-    """Smallest k for which the float64 running sum of k additions of ``free_inc``
+def pass_count_threshold(free_inc=0.01, thresh=10.0, base=0.0):
+    """Smallest k for which the float64 running sum ``base`` + k additions of ``free_inc``
     exceeds ``thresh`` (mapping.py:43,47): 1001 for (0.01, 10) because the
     sequential sum of 1000 x 0.01 is 9.99999999999983."""
-    acc, k = 0.0, 0
+    acc, k = base, 0
     while not acc > thresh:
         acc += free_inc
         k += 1
     return k
+
+
+def occupied_rule(free_inc=0.01, hit_inc=20.0, thresh=10.0):
+    """The canonical integer rule behind ``pmap`` (include/slam_hip.h, slam_grid_create): a
+    cell with h hits and p passes is occupied iff h >= len(table) or p >= table[h], where the
+    float sum is taken hits first.  [1001] for the reference's +20; [1001, 601, 201]-ish for
+    the +4 of w12-mapping-online (W12o/mapping.py:46), whose own answer depends on the order
+    of arrival when p is exactly table[h] - 1 or table[h]."""
+    table, base = [], 0.0
+    while not base > thresh:
+        table.append(pass_count_threshold(free_inc, thresh, base))
+        base += hit_inc
+    return table
 
 
 class Mapping:
@@ -284,12 +297,25 @@ class Mapping:
                     self.pmap[lpx][lpy] = 100 if self.datamap[lpx][lpy] > self.thresh else 0
         return self.pmap
 
+    def order_sensitive_cells(self):
+        """Cells whose reference answer depends on the arrival order of +hit and +free (only
+        possible when hit_inc <= thresh): h >= 1 hits below the last level and p exactly on
+        the canonical threshold or one below it."""
+        table = occupied_rule(self.free_inc, self.hit_inc, self.thresh)
+        m = np.zeros(self.pass_cnt.shape, dtype=bool)
+        for h, t in enumerate(table):
+            if h >= 1:
+                m |= (self.hit_cnt == h) & ((self.pass_cnt == t) | (self.pass_cnt == t - 1))
+        return m
+
     def pmap_from_counts(self):
-        """The integer rule the HIP finalize kernel applies:
-        untouched -> 50; hit >= 1 or pass >= k* -> 100; else 0."""
-        kstar = pass_count_threshold(self.free_inc, self.thresh)
+        """The integer rule the HIP finalize kernel applies (SURVEY.md a-10): untouched -> 50;
+        occupied per :func:`occupied_rule` -> 100 (for +20: hit >= 1 or pass >= 1001); else 0."""
+        table = occupied_rule(self.free_inc, self.hit_inc, self.thresh)
         touched = (self.pass_cnt + self.hit_cnt) > 0
-        occ = (self.hit_cnt >= 1) | (self.pass_cnt >= kstar)
+        occ = self.hit_cnt >= len(table)
+        for h, t in enumerate(table):
+            occ |= (self.hit_cnt == h) & (self.pass_cnt >= t)
         return np.where(touched, np.where(occ, 100, 0), 50).astype(np.int8)
 
 

@@ -289,12 +289,35 @@ long orc_grid_update(orc_grid *g, const double *ox, const double *oy, int n, dou
 
 /* Smallest k whose float64 running sum of k additions of free_inc exceeds thresh
  * (mapping.py:43,47): 1001 for (0.01, 10). */
-int orc_pass_count_threshold(double free_inc, double thresh)
+static int pass_threshold_from(double base, double free_inc, double thresh)
 {
-    double acc = 0.0;
+    double acc = base;
     int k = 0;
     while (!(acc > thresh)) { acc += free_inc; ++k; }
     return k;
+}
+
+int orc_pass_count_threshold(double free_inc, double thresh) { return pass_threshold_from(0.0, free_inc, thresh); }
+
+/* Canonical integer rule behind pmap (include/slam_hip.h, slam_grid_create): h hits and p
+ * passes are occupied iff h >= levels or p >= table[h]; the float sum is taken hits first.
+ * Returns levels (<= cap). */
+int orc_occupied_rule(double free_inc, double hit_inc, double thresh, int *table, int cap)
+{
+    double base = 0.0;
+    int levels = 0;
+    while (!(base > thresh) && levels < cap) {
+        table[levels++] = pass_threshold_from(base, free_inc, thresh);
+        base += hit_inc;
+    }
+    return levels;
+}
+
+static int8_t occupied_value(uint32_t ps, uint32_t ht, const int *table, int levels)
+{
+    if (!(ps | ht)) return 50;
+    if (ht >= (uint32_t)levels) return 100;
+    return ps >= (uint32_t)table[ht] ? 100 : 0;
 }
 
 /* W12m/slam_ekf.py:270-271: data[y*width + x] = int8(trunc(pmap[x][y])). */
@@ -408,12 +431,13 @@ long orc_replay_mt(const float *ranges, int n_scan, int n, const double *cos_t, 
             visits += grid_update_counts(g, ox, oy, n, p[0], p[1]);
             free(ox);
         }
-        int kstar = orc_pass_count_threshold(g->free_inc, g->thresh);
+        int table[64];
+        int levels = orc_occupied_rule(g->free_inc, g->hit_inc, g->thresh, table, 64);
         size_t cells = (size_t)g->xw * g->yw;
 #pragma omp parallel for num_threads(threads)
         for (size_t c = 0; c < cells; ++c) {
             uint32_t ps = g->pass_cnt[c], ht = g->hit_cnt[c];
-            g->pmap[c] = (ps | ht) ? ((ht >= 1 || ps >= (uint32_t)kstar) ? 100 : 0) : 50;
+            g->pmap[c] = occupied_value(ps, ht, table, levels);
         }
     }
     free(px); free(py);

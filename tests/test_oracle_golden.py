@@ -283,3 +283,75 @@ def test_map_observation(g5):
         src = on.laser_to_numpy(g5["obs_ranges"][k], -3.14159, 3.14159)
         T = on.map_observation(g5["obs_wall"], g5["obs_xest"][k], src, -3.14159, 3.14159, inc)
         assert np.max(np.abs(T - g5["obs_T"][k])) < FTOL
+
+
+# ------------------------------------------------------------------ w12-mapping-online (G6)
+@pytest.fixture(scope="module")
+def g6():
+    from conftest import load_golden
+    return load_golden("g6_mapping_online.npz")
+
+
+def test_occupied_rule_tables():
+    assert on.occupied_rule() == [1001]
+    assert on.occupied_rule(0.01, 4.0, 10.0) == [1001, 601, 201]
+    import ctypes as C
+    tab = (C.c_int * 8)()
+    L = co.lib()
+    L.orc_occupied_rule.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int]
+    assert L.orc_occupied_rule(0.01, 4.0, 10.0, tab, 8) == 3 and list(tab[:3]) == [1001, 601, 201]
+    assert L.orc_occupied_rule(0.01, 20.0, 10.0, tab, 8) == 1 and tab[0] == 1001
+
+
+def test_mapping_online_replay_golden(g6):
+    """The float restatement with hit_inc=4 follows the reference's +4 variant bit for bit
+    (same order of adds), and the canonical integer rule gives the same map."""
+    m = on.Mapping(200, 200, 0.1, hit_inc=4.0)
+    snaps = {int(k): i for i, k in enumerate(g6["snap_steps"])}
+    for k in range(g6["ox"].shape[0]):
+        pmap = m.update(g6["ox"][k], g6["oy"][k], g6["centres"][k, 0], g6["centres"][k, 1])
+        if k in snaps:
+            assert np.array_equal(pmap.astype(np.int8), g6["pmap_snaps"][snaps[k]]), k
+            assert np.array_equal(m.pmap_from_counts(), g6["pmap_snaps"][snaps[k]]), k
+    assert np.array_equal(m.datamap, g6["datamap"])
+
+
+def test_mapping_online_stress_golden(g6):
+    m = on.Mapping(200, 200, 0.1, hit_inc=4.0)
+    off = np.concatenate([[0], np.cumsum(g6["stress_len"])])
+    cx, cy = g6["stress_centre"]
+    for k in range(len(off) - 1):
+        m.update(g6["stress_ox"][off[k]:off[k + 1]], g6["stress_oy"][off[k]:off[k + 1]], cx, cy)
+    assert np.array_equal(m.pmap.astype(np.int8), g6["stress_pmap"])
+    assert np.array_equal(m.datamap, g6["stress_datamap"])
+    can = m.pmap_from_counts()
+    sens = m.order_sensitive_cells()
+    assert np.array_equal(can[~sens], g6["stress_pmap"][~sens])
+    # every level of the rule is exercised: occupied by passes alone with 0, 1 and 2 hits
+    for h, t in enumerate(on.occupied_rule(0.01, 4.0, 10.0)):
+        sel = m.hit_cnt == h
+        assert np.any(sel & (m.pass_cnt >= t)) and np.any(sel & (m.pass_cnt < t) & (m.pass_cnt > 0)), h
+    assert np.any(m.hit_cnt >= 3)
+
+
+def test_mapping_online_boundary_golden(g6):
+    """On a threshold the reference's answer depends on arrival order; the canonical rule is
+    the hits-first answer and flags exactly those cells as order-sensitive."""
+    X = tuple(int(v) for v in g6["boundary_cell"])
+    far, at = (np.array([5.05]), np.array([0.05])), (np.array([3.05]), np.array([0.05]))
+    seen_split = False
+    for h, p, hits_first, ref_pmap, ref_data in g6["boundary_cases"]:
+        h, p = int(h), int(p)
+        m = on.Mapping(200, 200, 0.1, hit_inc=4.0)
+        seq = [at] * h + [far] * p if hits_first else [far] * p + [at] * h
+        for ox, oy in seq:
+            m.update(ox, oy, 0.05, 0.05)
+        assert (m.hit_cnt[X], m.pass_cnt[X]) == (h, p)
+        assert m.pmap[X] == ref_pmap and m.datamap[X] == ref_data       # float path == reference, either order
+        can = m.pmap_from_counts()[X]
+        if hits_first:
+            assert can == ref_pmap
+        elif can != ref_pmap:
+            seen_split = True
+            assert m.order_sensitive_cells()[X]
+    assert seen_split        # (2 hits, 200 passes) really is order-dependent in the reference

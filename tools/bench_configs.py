@@ -88,6 +88,49 @@ def replay(slam, torch, scans, beams, grid_n, reso, room, points, steps, warmup,
             "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
 
 
+def mapobs(slam, torch, B, steps, warmup):
+    """B pose hypotheses of one 360-beam scan against the virtual scan of a
+    32k-obstacle map (tests/golden/g5 map): slam_virtual_scan_dev alone and the fused
+    slam_map_observation_dev (virtual scan -> points -> ICP)."""
+    A = slam._abi
+    dev = torch.device("cuda", 0)
+    ctx = A.Context(0, torch.cuda.current_stream(dev).cuda_stream)
+    g5 = np.load(os.path.join(ROOT, "tests", "golden", "g5_map_observation.npz"))
+    obs = g5["obstacle"]
+    K, n = obs.shape[1], 360
+    rng = np.random.default_rng(4)
+    true_pose = np.array([0.5, 0.3, 0.2])
+    poses = true_pose + rng.normal(0, [0.1, 0.1, 0.03], size=(B, 3))
+    r = slam.synthetic.scans_from_poses(slam.synthetic.World.room(1.0), true_pose[None], n, 5)[0]
+    ct, st = A.trig_tables(AMIN, AMAX, n)
+    src = np.stack([ct * r.astype(np.float64), st * r.astype(np.float64)])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ox, oy, dp, dsrc, dc, ds = d(obs[0]), d(obs[1]), d(poses), d(src), d(ct), d(st)
+    vr = torch.empty((B, n), dtype=torch.float64, device=dev)
+    vp = torch.empty((B, 2, n), dtype=torch.float64, device=dev)
+    T = torch.empty((B, 9), dtype=torch.float64, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev)
+    L = A.lib()
+    inc = (AMAX - AMIN) / (n - 1)
+
+    def vs():
+        A.check(L.slam_virtual_scan_dev(ctx.handle, ox.data_ptr(), oy.data_ptr(), K, dp.data_ptr(), B, AMIN, inc, n,
+                                        vr.data_ptr()))
+
+    def full():
+        A.check(L.slam_map_observation_dev(ctx.handle, ox.data_ptr(), oy.data_ptr(), K, dp.data_ptr(), dsrc.data_ptr(),
+                                           B, n, 1, dc.data_ptr(), ds.data_ptr(), AMIN, inc, 30, 1e-3, vr.data_ptr(),
+                                           vp.data_ptr(), T.data_ptr(), it.data_ptr()))
+
+    dt_vs = timed(vs, steps, warmup, torch)
+    dt = timed(full, steps, warmup, torch)
+    ctx.check_status()
+    return {"config": "8f-1: %d pose hypotheses, 360-beam scan vs virtual scan of a %d-obstacle map" % (B, K),
+            "value": B / dt, "unit": "map-observations/s", "ms_per_step": dt * 1e3, "mean_iters": float(it.float().mean()),
+            "virtual_scan_ms": dt_vs * 1e3, "virtual_scan_projections_per_s": B * K / dt_vs,
+            "virtual_scan_algorithmic_GBps": (B * K * 16 + B * n * 8) / dt_vs / 1e9}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="particles,dense,long")
@@ -100,6 +143,8 @@ def main():
     for w in args.which.split(","):
         if w == "particles":
             out = particles(slam, torch, args.particles, args.steps, args.warmup)
+        elif w == "mapobs":
+            out = mapobs(slam, torch, 4096, args.steps, args.warmup)
         elif w == "dense":
             out = replay(slam, torch, 1000, 1080, 2000, 0.02, 2.0, "f16", args.steps, args.warmup,
                          "configs[4]: 1k-scan replay, 1080 beams, 2000x2000@0.02m grid, f16 point buffers, room x2")
