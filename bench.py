@@ -16,8 +16,10 @@ fused in) -> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of 
 scans per second (one ICP.process + one Mapping.update each), summed over all ranks.
 
 With N > 1 every rank replays its own trajectory (seed 1 + rank; weak scaling, no
-data-path collective) and each step ends with one RCCL all_gather of the ranks' final
-poses (3 float64 each), the only exchange BASELINE.json configs[3] has.
+data-path collective); the ranks' final poses (3 float64 per replay) are exchanged with RCCL
+all_gather, the only exchange BASELINE.json configs[3] has: one collective for all K
+replays at the end of the timed region (--gather end, default) or one asynchronous
+all_gather per replay (--gather step).
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside the
 library on the launch stream) and "cpu_baseline" (oracle/slam_oracle.c, the C port of the
@@ -60,6 +62,8 @@ def parse():
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
     ap.add_argument("--grid-mode", type=int, default=1, help="1: LDS-window ray casting (default), 0: direct global atomics")
     ap.add_argument("--grid-group", type=int, default=0, help="scans per workgroup in window mode (0: automatic)")
+    ap.add_argument("--gather", default="end", choices=["step", "end", "none"],
+                    help="N > 1: all_gather of final poses after every replay (async), once at the end, or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", action="store_true", help="also compare the GPU result with the oracle")
@@ -102,7 +106,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK and MASTER_ADDR set) the collective path is taken even
+    # for one rank, so that it can be rehearsed on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -114,18 +121,36 @@ def main():
     dr.ctx.set_option("grid_mode", args.grid_mode)
     dr.ctx.set_option("grid_group", args.grid_group)
     pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=dr.dev)
-    gathered = torch.empty(world * 3, dtype=torch.float64, device=dr.dev) if world > 1 else None
+    # N > 1: the ranks' final poses are all-gathered (RCCL), the only exchange BASELINE.json
+    # configs[3] has.  Every replay writes its poses into its own slot of a ring, so nothing
+    # is copied per step and the replay stream never waits for a collective.
+    #   --gather end  (default): ONE all_gather of all K replays' final poses at the end of
+    #                 the timed region (one larger collective instead of K latency-bound ones);
+    #   --gather step: one asynchronous all_gather per replay on RCCL's stream, overlapping
+    #                 the next replay; the fence waits for the last.
+    slots = args.steps + args.warmup
+    ring = torch.empty((slots,) + tuple(dr.poses.shape), dtype=torch.float64, device=dr.dev) if use_dist else None
+    gathered = torch.empty((slots, world * 3), dtype=torch.float64, device=dr.dev) if use_dist else None
+    gathered_all = torch.empty(world * slots * 3, dtype=torch.float64, device=dr.dev) if use_dist else None
+    pending = []
+    done = [0]
     L = slam._abi.lib()
 
     def step():
-        dr.run(reset_grid=True)
+        slot = done[0]
+        done[0] += 1
+        dr.run(reset_grid=True, poses_out=ring[slot] if use_dist else None)
         slam._abi.check(L.slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, dr.poses[0, -1].reshape(3).contiguous())
+        if use_dist and args.gather == "step":
+            pending.append(dist.all_gather_into_tensor(gathered[slot], ring[slot, 0, -1], async_op=True))
 
     def fence():
+        if use_dist and args.gather == "end":
+            dist.all_gather_into_tensor(gathered_all, ring[:, 0, -1, :].contiguous().reshape(-1))
+        if use_dist and pending:
+            pending[-1].wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -136,11 +161,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enqueue = time.perf_counter() - t0      # host time to enqueue all steps (launch-bound if ~ elapsed)
     fence()
     elapsed = time.perf_counter() - t0
     fam = dr.ctx.timing_read()
     dr.ctx.timing_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dr.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -190,12 +216,13 @@ def main():
     out = {
         "metric": "scans/sec (360-beam ICP + 0.05 m grid update)", "value": value, "unit": "scans/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "configs[1]: %d-scan replay (every %dth message of a 10 Hz stream), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid"
                                % (args.scans, args.stride, args.beams, args.max_iter, args.tol, args.grid, args.grid, args.reso),
                    "scans_per_step_per_gpu": scans_per_step, "point_buffers": args.points, "trajectories_per_gpu": 1,
                    "grid_mode": args.grid_mode, "grid_group": args.grid_group,
-                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses per step" if world > 1 else "")},
+                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if world > 1 else "")},
         "roofline": roofline,
     }
     if args.check and rank == 0:
@@ -210,7 +237,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(rep, args, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
