@@ -78,6 +78,20 @@ struct slam_ctx {
     int64_t launches[SLAM_K_COUNT] = {0};
     int grid_mode = 1;    // 0: direct global atomics, 1: LDS window
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
+    // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
+    // a second stream, so the map stage of one replay overlaps the scan matching of the next.
+    int pipeline = 0;
+    hipStream_t gstream = nullptr;                   // map stage
+    hipStream_t cstream = nullptr;                   // pose composition (a serial chain in one workgroup)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_icp = nullptr, ev_pose = nullptr;
+    hipEvent_t ev_cast[2] = {nullptr, nullptr};     // "compose + ray cast of that replay have read T / poses"
+    const void *cast_poses[2] = {nullptr, nullptr};
+    const void *cast_T[2] = {nullptr, nullptr};
+    double *pipe_T[2] = {nullptr, nullptr};          // T buffers when the caller passes none
+    size_t pipe_T_bytes = 0;
+    int cast_pos = 0;
+    bool gdirty = false;                             // work on gstream the main stream has not waited for
+    bool mgrid = false;                              // map work on the main stream gstream has not waited for
 };
 
 struct slam_grid {
@@ -117,18 +131,19 @@ T *carve(Arena &a, size_t count)
 struct Timed {
     slam_ctx *c;
     int kind;
+    hipStream_t st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    Timed(slam_ctx *ctx, int k) : c(ctx), kind(k)
+    Timed(slam_ctx *ctx, int k, hipStream_t on = nullptr) : c(ctx), kind(k), st(on ? on : ctx->stream)
     {
         if (!c->timing) return;
         e0 = get();
         e1 = get();
-        if (e0 && e1) (void)hipEventRecord(e0, c->stream);
+        if (e0 && e1) (void)hipEventRecord(e0, st);
     }
     ~Timed()
     {
         if (!c->timing || !e0 || !e1) return;
-        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventRecord(e1, st);
         c->pending.push_back({kind, e0, e1});
     }
     hipEvent_t get()
@@ -151,6 +166,37 @@ int use(slam_ctx *c)
     return SLAM_OK;
 }
 
+// stream of the pipelined map stage
+hipStream_t gs(slam_ctx *c) { return c->pipeline ? c->gstream : c->stream; }
+
+// the map stream must see everything enqueued on the main stream so far
+int fork_to_grid(slam_ctx *c)
+{
+    if (!c->pipeline) return SLAM_OK;
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->gstream, c->ev_fork, 0));
+    c->gdirty = true;
+    return SLAM_OK;
+}
+
+// the main stream must see everything enqueued on the map stream so far
+int join_from_grid(slam_ctx *c)
+{
+    if (!c->pipeline || !c->gdirty) return SLAM_OK;
+    HIPCHK(hipEventRecord(c->ev_join, c->gstream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->gdirty = false;
+    return SLAM_OK;
+}
+
+// entry points that touch a map on the MAIN stream call this first
+int grid_on_main(slam_ctx *c)
+{
+    if (!c->pipeline) return SLAM_OK;
+    c->mgrid = true;
+    return join_from_grid(c);
+}
+
 int status_to_code(int st)
 {
     if (st & kStatusNaN) return fail(SLAM_ERR_NAN, "cannot convert float NaN to integer (mapping.py:33-36)");
@@ -162,6 +208,7 @@ int status_to_code(int st)
 int check_status_sync(slam_ctx *c)
 {
     int st = 0;
+    if (int rc = join_from_grid(c)) return rc;
     HIPCHK(hipMemcpyAsync(&st, c->status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (st) {
@@ -231,6 +278,16 @@ int slam_destroy(slam_ctx *c)
     if (!c) return SLAM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->gstream) {
+        (void)hipStreamSynchronize(c->cstream);
+        (void)hipStreamSynchronize(c->gstream);
+        (void)hipStreamDestroy(c->cstream);
+        (void)hipStreamDestroy(c->gstream);
+        for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_icp, c->ev_pose, c->ev_cast[0], c->ev_cast[1]})
+            if (e) (void)hipEventDestroy(e);
+        for (double *t : c->pipe_T)
+            if (t) (void)hipFree(t);
+    }
     for (auto &p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->staging.base) (void)hipFree(c->staging.base);
@@ -244,6 +301,7 @@ int slam_destroy(slam_ctx *c)
 int slam_synchronize(slam_ctx *c)
 {
     TRY(use(c));
+    TRY(join_from_grid(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SLAM_OK;
 }
@@ -260,6 +318,20 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     REQUIRE(name, "null name");
     if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1, "grid_mode is 0 or 1"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
+    else if (!strcmp(name, "pipeline")) {
+        REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
+        TRY(join_from_grid(c));
+        if (value == 1 && !c->gstream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&c->ev_fork, &c->ev_join, &c->ev_icp, &c->ev_pose, &c->ev_cast[0], &c->ev_cast[1]})
+                HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        if (value == 0 && c->pipeline) HIPCHK(hipStreamSynchronize(c->gstream));
+        c->pipeline = (int)value;
+        c->cast_poses[0] = c->cast_poses[1] = nullptr;
+        c->cast_T[0] = c->cast_T[1] = nullptr;
+    }
     else return fail(SLAM_ERR_INVALID, "unknown option %s", name);
     return SLAM_OK;
 }
@@ -267,6 +339,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
 int slam_timing_enable(slam_ctx *c, int on)
 {
     TRY(use(c));
+    TRY(join_from_grid(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &p : c->pending) { c->pool.push_back(p.e0); c->pool.push_back(p.e1); }
     c->pending.clear();
@@ -540,6 +613,7 @@ int slam_grid_destroy(slam_ctx *c, slam_grid *g)
     if (c) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        if (c->gstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamSynchronize(c->gstream); }
     }
     if (g->d.pass) (void)hipFree(g->d.pass);   // also holds hit[] and the visit counter
     if (g->pmap_one) (void)hipFree(g->pmap_one);
@@ -552,7 +626,12 @@ int slam_grid_reset(slam_ctx *c, slam_grid *g)
 {
     TRY(use(c));
     REQUIRE(g, "null grid");
-    HIPCHK(hipMemsetAsync(g->d.pass, 0, g->state_bytes, c->stream));
+    if (c->pipeline && c->mgrid) {
+        TRY(fork_to_grid(c));
+        c->mgrid = false;
+    }
+    HIPCHK(hipMemsetAsync(g->d.pass, 0, g->state_bytes, gs(c)));
+    if (c->pipeline) c->gdirty = true;
     return SLAM_OK;
 }
 
@@ -560,6 +639,7 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
                          int B, int n, const int32_t *grid_of_batch)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(g && ox && oy && cx && cy, "null pointer");
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
     Timed t(c, SLAM_K_GRID);
@@ -596,6 +676,7 @@ int slam_grid_update_scans_dev(slam_ctx *c, slam_grid *g, const float *ranges, c
                                const double *poses, const double *centres, int S, int n)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(g && ranges && cos_t && sin_t && poses, "null pointer");
     REQUIRE(S > 0 && n > 0 && n <= 65535, "bad sizes");
     Timed t(c, SLAM_K_GRID);
@@ -629,14 +710,16 @@ int slam_grid_finalize_dev(slam_ctx *c, slam_grid *g, int8_t *pmap_dev)
 {
     TRY(use(c));
     REQUIRE(g && pmap_dev, "null pointer");
-    Timed t(c, SLAM_K_FINALIZE);
-    HIPCHK(launch_grid_finalize(g->d, 0, g->d.G, pmap_dev, c->stream));
+    TRY(fork_to_grid(c));          // pmap_dev may still be in use by work on the main stream
+    Timed t(c, SLAM_K_FINALIZE, gs(c));
+    HIPCHK(launch_grid_finalize(g->d, 0, g->d.G, pmap_dev, gs(c)));
     return SLAM_OK;
 }
 
 int slam_grid_read(slam_ctx *c, slam_grid *g, int gi, int8_t *pmap, double *datamap, uint32_t *pass, uint32_t *hit)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(g, "null grid");
     REQUIRE(gi >= 0 && gi < g->d.G, "grid index out of range");
     size_t per = (size_t)g->d.xw * g->d.yw;
@@ -660,6 +743,7 @@ int slam_grid_read(slam_ctx *c, slam_grid *g, int gi, int8_t *pmap, double *data
 int slam_grid_occupancy_data(slam_ctx *c, slam_grid *g, int gi, int8_t *data)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(g && data, "null pointer");
     REQUIRE(gi >= 0 && gi < g->d.G, "grid index out of range");
     size_t per = (size_t)g->d.xw * g->d.yw;
@@ -675,6 +759,7 @@ int slam_grid_occupancy_data(slam_ctx *c, slam_grid *g, int gi, int8_t *data)
 int slam_grid_visits(slam_ctx *c, slam_grid *g, uint64_t *visits_out)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(g && visits_out, "null pointer");
     unsigned long long v = 0;
     D2H(&v, g->visits, sizeof v);
@@ -733,11 +818,35 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
     REQUIRE(n <= 8192, "n too large (max 8192 beams)");
     const long pairs = (long)L * (n_scan - 1);
     REQUIRE(pairs < (1L << 31), "too many scan pairs for one launch");
+    const bool piped = c->pipeline && grid;     // three stages on three streams: ICP | compose | map
     double *T = T_out;
     if (!T) {
-        TRY(arena_reserve(c, c->scratch, align_up((size_t)pairs * 72) + 1024));
-        T = carve<double>(c->scratch, (size_t)pairs * 9);
+        if (piped) {                            // two alternating buffers: compose of replay k reads T while ICP k+1 runs
+            size_t need = align_up((size_t)pairs * 72);
+            if (need > c->pipe_T_bytes) {
+                TRY(join_from_grid(c));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                for (double *&t : c->pipe_T) {
+                    if (t) HIPCHK(hipFree(t));
+                    t = nullptr;
+                    if (hipMalloc(reinterpret_cast<void **>(&t), need) != hipSuccess)
+                        return fail(SLAM_ERR_NOMEM, "hipMalloc(%zu bytes) for T", need);
+                }
+                c->pipe_T_bytes = need;
+            }
+            T = c->pipe_T[c->cast_pos];
+        } else {
+            TRY(arena_reserve(c, c->scratch, align_up((size_t)pairs * 72) + 1024));
+            T = carve<double>(c->scratch, (size_t)pairs * 9);
+        }
     }
+    if (c->pipeline)        // is an earlier replay's compose / ray cast still reading these buffers?
+        for (int k = 0; k < 2; ++k)
+            if (c->cast_poses[k] && (c->cast_poses[k] == poses_out || c->cast_T[k] == T)) {
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_cast[k], 0));
+                HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_cast[k], 0));
+                c->cast_poses[k] = c->cast_T[k] = nullptr;
+            }
     {
         // polar -> Cartesian is fused into the ICP kernel: scan k-1 / k of stream l are read as raw
         // ranges and turned into points (of storage type `dtype`) in registers
@@ -752,18 +861,45 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }
-    {
-        Timed t(c, SLAM_K_COMPOSE);
-        HIPCHK(launch_pose_compose(T, pose0, L, n_scan - 1, poses_out, c->stream));
+    if (!piped) {
+        {
+            Timed t(c, SLAM_K_COMPOSE);
+            HIPCHK(launch_pose_compose(T, pose0, L, n_scan - 1, poses_out, c->stream));
+        }
+        if (grid) {
+            TRY(grid_on_main(c));
+            Timed t(c, SLAM_K_GRID);
+            if (c->grid_mode == 1)
+                HIPCHK(launch_grid_update_replay_win(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj,
+                                                     c->grid_group, c->stream));
+            else
+                HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
+        }
+        return SLAM_OK;
     }
-    if (grid) {
-        Timed t(c, SLAM_K_GRID);
+    // compose waits for the ICP (and everything before it on the main stream: pose0, ranges)
+    HIPCHK(hipEventRecord(c->ev_icp, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_icp, 0));
+    {
+        Timed t(c, SLAM_K_COMPOSE, c->cstream);
+        HIPCHK(launch_pose_compose(T, pose0, L, n_scan - 1, poses_out, c->cstream));
+    }
+    HIPCHK(hipEventRecord(c->ev_pose, c->cstream));
+    HIPCHK(hipStreamWaitEvent(c->gstream, c->ev_pose, 0));
+    c->gdirty = true;
+    c->mgrid = false;
+    {
+        Timed t(c, SLAM_K_GRID, c->gstream);
         if (c->grid_mode == 1)
             HIPCHK(launch_grid_update_replay_win(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj,
-                                                 c->grid_group, c->stream));
+                                                 c->grid_group, c->gstream));
         else
-            HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
+            HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->gstream));
     }
+    HIPCHK(hipEventRecord(c->ev_cast[c->cast_pos], c->gstream));
+    c->cast_poses[c->cast_pos] = poses_out;
+    c->cast_T[c->cast_pos] = T;
+    c->cast_pos ^= 1;
     return SLAM_OK;
 }
 
@@ -808,6 +944,7 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
                        void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
 {
     TRY(use(c));
+    TRY(grid_on_main(c));
     REQUIRE(ranges2 && cos_t && sin_t && pose_prev && poses_out && T_out, "null pointer");
     (void)pts_ws;   // kept in the ABI; the point buffers are no longer materialised
     REQUIRE(P > 0 && n > 0 && n <= 8192, "need P > 0 and 0 < n <= 8192");

@@ -211,14 +211,18 @@ class DeviceReplay:
         self.grid = DeviceGrid.metric(G, xw, yw, reso, context=self.ctx, **kw)
         return self.grid
 
-    def run(self, reset_grid=True, poses_out=None):
-        """One pass.  ``poses_out``: optional float64 device tensor [L, n_scan-1, 3] to receive
-        the poses instead of ``self.poses`` (e.g. one slot of a ring, so that finished replays
-        can be gathered later without a copy); it becomes ``self.poses``."""
-        if poses_out is not None:
-            if tuple(poses_out.shape) != tuple(self.poses.shape) or poses_out.dtype != self.poses.dtype or not poses_out.is_contiguous():
-                raise ValueError("poses_out must be a contiguous float64 tensor of shape %r" % (tuple(self.poses.shape),))
-            self.poses = poses_out
+    def run(self, reset_grid=True, poses_out=None, T_out=None):
+        """One pass.  ``poses_out`` / ``T_out``: optional float64 device tensors
+        [L, n_scan-1, 3] / [L*(n_scan-1), 9] to receive the poses / transforms instead of
+        ``self.poses`` / ``self.T`` (e.g. slots of a ring: with the context's "pipeline" option
+        consecutive replays overlap only if they write different buffers); they become
+        ``self.poses`` / ``self.T``."""
+        for name, buf in (("poses", poses_out), ("T", T_out)):
+            if buf is not None:
+                cur = getattr(self, name)
+                if tuple(buf.shape) != tuple(cur.shape) or buf.dtype != cur.dtype or not buf.is_contiguous():
+                    raise ValueError("%s_out must be a contiguous float64 tensor of shape %r" % (name, tuple(cur.shape)))
+                setattr(self, name, buf)
         if self.grid is not None and reset_grid:
             self.grid.reset()
         _abi.check(_abi.lib().slam_replay_dev(

@@ -62,6 +62,11 @@ def parse():
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
     ap.add_argument("--grid-mode", type=int, default=1, help="1: LDS-window ray casting (default), 0: direct global atomics")
     ap.add_argument("--grid-group", type=int, default=0, help="scans per workgroup in window mode (0: automatic)")
+    ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
+    ap.add_argument("--time-all-lanes", action="store_true", help="HIP events on every lane (default: lane 0 only)")
+    ap.add_argument("--lanes", type=int, default=4, help="contexts (stream sets) the replays alternate between")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
+                    help="1: map stage of a replay on a second stream, overlapping the next replay's scan matching")
     ap.add_argument("--gather", default="end", choices=["step", "end", "none"],
                     help="N > 1: all_gather of final poses after every replay (async), once at the end, or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,39 +121,65 @@ def main():
     slam = importlib.import_module(PKG)
 
     rep = slam.synthetic.make_replay(args.scans, args.beams, seed=1 + rank, room_scale=args.room_scale, stride=args.stride)
-    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol, dtype=args.points, device=local)
-    grid = dr.make_grid(1, args.grid, args.grid, args.reso)
-    dr.ctx.set_option("grid_mode", args.grid_mode)
-    dr.ctx.set_option("grid_group", args.grid_group)
-    pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=dr.dev)
-    # N > 1: the ranks' final poses are all-gathered (RCCL), the only exchange BASELINE.json
-    # configs[3] has.  Every replay writes its poses into its own slot of a ring, so nothing
-    # is copied per step and the replay stream never waits for a collective.
+    # Consecutive replays are independent, so they are overlapped two ways (results are
+    # unchanged, see --check):
+    #  * --lanes 4 (default): replays alternate between four contexts (own stream, own map and
+    #    output buffers; the GPU exposes four hardware queues per process), so one replay's
+    #    latency-bound stretches (kernel tails, the ray cast) are filled by the others' work;
+    #  * --pipeline 1: inside a context the library runs scan matching, pose composition and
+    #    the map stage (reset -> ray cast -> finalize) on three HIP streams, so the map stage of
+    #    one replay overlaps the scan matching of the next (4.3 M scans/s with one lane; with
+    #    four lanes the extra streams oversubscribe the hardware queues, hence off by default).
+    # Every replay writes its poses into its own slot of a ring (T into one of two buffers per
+    # lane).  N > 1: the ranks' final poses are all-gathered (RCCL), the only exchange
+    # BASELINE.json configs[3] has; nothing is copied per step and no replay stream ever waits
+    # for a collective.
     #   --gather end  (default): ONE all_gather of all K replays' final poses at the end of
     #                 the timed region (one larger collective instead of K latency-bound ones);
-    #   --gather step: one asynchronous all_gather per replay on RCCL's stream, overlapping
-    #                 the next replay; the fence waits for the last.
+    #   --gather step: one all_gather per replay (synchronises the lane first).
+    class Lane:
+        pass
+
+    lanes = []
+    for _ in range(max(1, args.lanes)):
+        ln = Lane()
+        ln.stream = torch.cuda.Stream(device=local) if args.lanes > 1 else torch.cuda.current_stream(local)
+        with torch.cuda.stream(ln.stream):
+            ln.dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
+                                      dtype=args.points, device=local)
+            ln.grid = ln.dr.make_grid(1, args.grid, args.grid, args.reso)
+            ln.pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
+            ln.ring_T = torch.empty((2,) + tuple(ln.dr.T.shape), dtype=torch.float64, device=ln.dr.dev)
+        ln.dr.ctx.set_option("grid_mode", args.grid_mode)
+        ln.dr.ctx.set_option("grid_group", args.grid_group)
+        ln.dr.ctx.set_option("pipeline", args.pipeline)
+        ln.count = 0
+        lanes.append(ln)
+    dr = lanes[0].dr
     slots = args.steps + args.warmup
-    ring = torch.empty((slots,) + tuple(dr.poses.shape), dtype=torch.float64, device=dr.dev) if use_dist else None
+    ring = torch.empty((slots,) + tuple(dr.poses.shape), dtype=torch.float64, device=dr.dev)
     gathered = torch.empty((slots, world * 3), dtype=torch.float64, device=dr.dev) if use_dist else None
     gathered_all = torch.empty(world * slots * 3, dtype=torch.float64, device=dr.dev) if use_dist else None
-    pending = []
+    torch.cuda.synchronize()
     done = [0]
     L = slam._abi.lib()
 
     def step():
         slot = done[0]
         done[0] += 1
-        dr.run(reset_grid=True, poses_out=ring[slot] if use_dist else None)
-        slam._abi.check(L.slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
+        ln = lanes[slot % len(lanes)]
+        ln.dr.run(reset_grid=True, poses_out=ring[slot], T_out=ln.ring_T[ln.count & 1])
+        ln.count += 1
+        slam._abi.check(L.slam_grid_finalize_dev(ln.dr.ctx.handle, ln.grid._h, ln.pmap.data_ptr()))
         if use_dist and args.gather == "step":
-            pending.append(dist.all_gather_into_tensor(gathered[slot], ring[slot, 0, -1], async_op=True))
+            ln.dr.ctx.synchronize()
+            dist.all_gather_into_tensor(gathered[slot], ring[slot, 0, -1])
 
     def fence():
+        for ln in lanes:
+            ln.dr.ctx.synchronize()        # joins the lane's compose / map streams
         if use_dist and args.gather == "end":
             dist.all_gather_into_tensor(gathered_all, ring[:, 0, -1, :].contiguous().reshape(-1))
-        if use_dist and pending:
-            pending[-1].wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -157,15 +188,26 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    dr.ctx.timing_enable(True)
+    # HIP events bracket every kernel of lane 0 (every len(lanes)-th replay of the timed region);
+    # bracketing all lanes costs ~5 % throughput in event markers.
+    timed_lanes = lanes if args.time_all_lanes else lanes[:1]
+    for ln in timed_lanes:
+        ln.dr.ctx.timing_enable(not args.no_timing)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     enqueue = time.perf_counter() - t0      # host time to enqueue all steps (launch-bound if ~ elapsed)
     fence()
     elapsed = time.perf_counter() - t0
-    fam = dr.ctx.timing_read()
-    dr.ctx.timing_enable(False)
+    fam = {}
+    for ln in timed_lanes:                 # HIP-event times per kernel family
+        for k, v in ln.dr.ctx.timing_read().items():
+            acc = fam.setdefault(k, [0.0, 0])
+            acc[0] += v[0]
+            acc[1] += v[1]
+        ln.dr.ctx.timing_enable(False)
+    last = lanes[(done[0] - 1) % len(lanes)]
+    dr, grid, pmap = last.dr, last.grid, last.pmap
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dr.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,6 +218,14 @@ def main():
     poses, T, iters = dr.results()
     total_scans = scans_per_step * world * args.steps
     value = total_scans / elapsed
+
+    if args.no_timing:
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": elapsed / args.steps * 1e3, "lanes": args.lanes,
+                              "pipeline": args.pipeline, "note": "experiment without HIP-event timing"}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     # ---- roofline of the dominant kernel (largest share of the HIP-event time) -----------
     ms = {k: v[0] for k, v in fam.items() if v[1] > 0}
@@ -201,7 +251,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "valu_busy_frac_pmc": valu_busy,   # SQ_ACTIVE_INST_VALU share of the kernel's SIMD cycles (profiles/)
                 "avg_launch_ms": dom_ms / dom_n, "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms_per_step": {k: fam[k][0] / args.steps for k in ms}}
+                "kernel_ms_per_step": {k: fam[k][0] / fam[k][1] for k in ms},
+                "timed": "HIP events on %d of %d lanes; durations include overlap with the other lanes' kernels"
+                         % (len(timed_lanes), len(lanes))}
     # ICP is VALU-bound, not HBM-bound.  The figure below counts the distance
     # evaluations an EXHAUSTIVE nearest-neighbour scan would make (iters * n_src * n_tar, what the
     # reference does); the pruned search returns the same result evaluating about a fifth of them.
@@ -221,7 +273,7 @@ def main():
         "config": {"workload": "configs[1]: %d-scan replay (every %dth message of a 10 Hz stream), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid"
                                % (args.scans, args.stride, args.beams, args.max_iter, args.tol, args.grid, args.grid, args.reso),
                    "scans_per_step_per_gpu": scans_per_step, "point_buffers": args.points, "trajectories_per_gpu": 1,
-                   "grid_mode": args.grid_mode, "grid_group": args.grid_group,
+                   "pipeline": args.pipeline, "lanes": args.lanes, "grid_mode": args.grid_mode, "grid_group": args.grid_group,
                    "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if world > 1 else "")},
         "roofline": roofline,
     }

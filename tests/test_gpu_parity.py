@@ -432,6 +432,53 @@ def test_full_size_replay(slam, syn):
     torch.cuda.synchronize()
 
 
+def test_pipelined_map_stage_is_bit_identical(slam, syn):
+    """"pipeline" option: the map stage on a second stream (overlapping the next replay's scan
+    matching) gives the same bits as the serial order, with alternating AND with reused pose
+    buffers, and with main-stream map calls interleaved."""
+    import torch
+    reps = [syn.make_replay(120, 360, seed=s, stride=5) for s in (3, 4)]
+    want = []
+    for rep in reps:                                         # serial reference
+        dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX)
+        grid = dr.make_grid(1, 400, 400, 0.05)
+        dr.run()
+        want.append((dr.results(), grid.read(0, want=("pmap", "pass", "hit")), grid.visits()))
+    A = slam._abi
+    drs = [slam.DeviceReplay(rep.ranges, AMIN, AMAX) for rep in reps]
+    ctx = drs[0].ctx
+    drs[1].ctx = ctx                                         # both replays on ONE context
+    ctx.set_option("pipeline", 1)
+    grid = drs[0].make_grid(1, 400, 400, 0.05)
+    drs[1].grid = grid
+    pmaps = [torch.empty((400, 400), dtype=torch.int8, device=drs[0].dev) for _ in range(6)]
+    bufs = [torch.empty_like(drs[0].poses) for _ in range(2)]
+    tbufs = [torch.empty_like(drs[0].T) for _ in range(2)]
+    for k in range(6):                                       # replays 3,4,3,4,3,4 back to back, no host sync
+        d = drs[k & 1]
+        d.run(reset_grid=True, poses_out=bufs[k & 1] if k < 4 else bufs[0],  # last two reuse ONE poses buffer,
+              T_out=tbufs[k & 1] if k < 2 else tbufs[0])                       # from the third on ONE T buffer
+        A.check(A.lib().slam_grid_finalize_dev(ctx.handle, grid._h, pmaps[k].data_ptr()))
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert np.array_equal(pmaps[k].cpu().numpy(), want[k & 1][1]["pmap"]), k
+    got = grid.read(0, want=("pmap", "pass", "hit"))          # a main-stream map call: joins the map stream
+    w = want[1]
+    assert np.array_equal(got["pass"], w[1]["pass"]) and np.array_equal(got["hit"], w[1]["hit"]) and grid.visits() == w[2]
+    assert np.array_equal(bufs[0].cpu().numpy(), w[0][0])
+    assert np.array_equal(tbufs[0].cpu().numpy().reshape(w[0][1].shape), w[0][1])
+    # map calls on the main stream between pipelined replays keep their order
+    m_ox = np.array([[1.0, 2.0, -3.0]]); m_oy = np.array([[0.5, -1.0, 2.0]])
+    grid.reset()
+    grid.update_host(m_ox, m_oy, np.array([0.0]), np.array([0.0]))
+    c1 = grid.read(0, want=("pass", "hit"))
+    grid.reset()
+    c0 = grid.read(0, want=("pass", "hit"))
+    assert c1["pass"].sum() > 0 and c1["hit"].sum() == 3 and c0["pass"].sum() == 0 and c0["hit"].sum() == 0
+    ctx.set_option("pipeline", 0)
+
+
 @pytest.mark.parametrize("group", [1, 2, 3, 8, 11, 64])
 def test_grid_window_modes_are_bit_identical(slam, syn, group):
     """The LDS-window ray caster (any group size, incl. windows smaller than the rays'
