@@ -200,7 +200,7 @@ static inline int ray_block(int n)
 hipError_t launch_grid_update(const GridDev &g, const double *ox, const double *oy, const double *cx, const double *cy,
                               int B, int n, const int32_t *gob, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_grid_update, dim3(B), dim3(ray_block(n)), 0, s, g, ox, oy, cx, cy, n, gob);
+    SLAM_LAUNCH(k_grid_update, dim3(B), dim3(ray_block(n)), 0, s, g, ox, oy, cx, cy, n, gob);
     return hipGetLastError();
 }
 
@@ -208,7 +208,7 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
                                      const double *poses, int L, int n_scan, int n, const int32_t *got, hipStream_t s)
 {
     if (n_scan < 2) return hipSuccess;
-    hipLaunchKernelGGL(k_grid_update_replay, dim3(n_scan - 1, L), dim3(ray_block(n)), 0, s, g, ranges, cos_t, sin_t,
+    SLAM_LAUNCH(k_grid_update_replay, dim3(n_scan - 1, L), dim3(ray_block(n)), 0, s, g, ranges, cos_t, sin_t,
                        poses, n_scan, n, got);
     return hipGetLastError();
 }
@@ -503,7 +503,7 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     long want = (rays + kRaysPerLane - 1) / kRaysPerLane;
     int threads = want >= 1024 ? 1024 : (int)(((want + kWave - 1) / kWave) * kWave);
     if (threads < 128) threads = 128;
-    hipLaunchKernelGGL((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got);
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got);
     return hipGetLastError();
 }
 
@@ -597,7 +597,7 @@ hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pm
     OccRule rule;
     rule.hit_levels = g.hit_levels;
     for (int k = 0; k < kMaxHitLevels; ++k) rule.pass_thresh[k] = g.pass_thresh[k];
-    hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells, rule, pmap);
+    SLAM_LAUNCH(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells, rule, pmap);
     return hipGetLastError();
 }
 
@@ -614,7 +614,7 @@ hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStr
     size_t per = (size_t)g.xw * g.yw;
     size_t blocks = (per + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_grid_datamap, dim3(blocks), dim3(256), 0, s, g.pass + per * gi, g.hit + per * gi, per, g.free_inc,
+    SLAM_LAUNCH(k_grid_datamap, dim3(blocks), dim3(256), 0, s, g.pass + per * gi, g.hit + per * gi, per, g.free_inc,
                        g.hit_inc, datamap);
     return hipGetLastError();
 }
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256) k_grid_transpose(const int8_t *__restrict
 
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_grid_transpose, dim3((xw + 31) / 32, (yw + 31) / 32), dim3(256), 0, s, pmap, xw, yw, data);
+    SLAM_LAUNCH(k_grid_transpose, dim3((xw + 31) / 32, (yw + 31) / 32), dim3(256), 0, s, pmap, xw, yw, data);
     return hipGetLastError();
 }
 
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) k_bresenham(const int32_t *__restrict__ s
 hipError_t launch_bresenham(const int32_t *starts, const int32_t *ends, int B, const int64_t *offsets, int32_t *lens,
                             int32_t *cells, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_bresenham, dim3((B + 255) / 256), dim3(256), 0, s, starts, ends, B, offsets, lens, cells);
+    SLAM_LAUNCH(k_bresenham, dim3((B + 255) / 256), dim3(256), 0, s, starts, ends, B, offsets, lens, cells);
     return hipGetLastError();
 }
 

@@ -430,7 +430,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL((k_icp<T, Q>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                        \
+        SLAM_LAUNCH((k_icp<T, Q>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                        \
     }
     if (qpt <= 1) SLAM_ICP_CASE(1)
     else if (qpt <= 2) SLAM_ICP_CASE(2)
@@ -490,7 +490,7 @@ static hipError_t launch_nn_t(const void *src, const void *tar, int B, int n_src
         if (e != hipSuccess) return e;
     }
     dim3 grid((n_src + 255) / 256, B);
-    hipLaunchKernelGGL((k_nn<T>), grid, dim3(256), lds, s, static_cast<const T *>(src), static_cast<const T *>(tar),
+    SLAM_LAUNCH((k_nn<T>), grid, dim3(256), lds, s, static_cast<const T *>(src), static_cast<const T *>(tar),
                        n_src, n_tar, dist, idx);
     return hipGetLastError();
 }
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) k_kabsch(const double *src, const double 
 
 hipError_t launch_kabsch(const double *src, const double *tar, int B, int n, double *T_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_kabsch, dim3(B), dim3(256), 0, s, src, tar, n, T_out);
+    SLAM_LAUNCH(k_kabsch, dim3(B), dim3(256), 0, s, src, tar, n, T_out);
     return hipGetLastError();
 }
 
@@ -569,13 +569,13 @@ hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const
     if (blocks < 1) blocks = 1;
     switch (dtype) {
     case SLAM_F64:
-        hipLaunchKernelGGL((k_scan_to_points<double>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<double *>(pts));
+        SLAM_LAUNCH((k_scan_to_points<double>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<double *>(pts));
         break;
     case SLAM_F32:
-        hipLaunchKernelGGL((k_scan_to_points<float>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<float *>(pts));
+        SLAM_LAUNCH((k_scan_to_points<float>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<float *>(pts));
         break;
     case SLAM_F16:
-        hipLaunchKernelGGL((k_scan_to_points<__half>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<__half *>(pts));
+        SLAM_LAUNCH((k_scan_to_points<__half>), dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, clip_inf, static_cast<__half *>(pts));
         break;
     default: return hipErrorInvalidValue;
     }
@@ -698,10 +698,10 @@ hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int 
 {
     if (prior || (n == 1 && L > 64)) {
         if (n != 1) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses);
+        SLAM_LAUNCH(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_pose_compose, dim3(L), dim3(kComposeThreads), 0, s, T, pose0, n, poses);
+    SLAM_LAUNCH(k_pose_compose, dim3(L), dim3(kComposeThreads), 0, s, T, pose0, n, poses);
     return hipGetLastError();
 }
 

@@ -107,7 +107,7 @@ hipError_t launch_map_obstacles(const int8_t *map, int width, int height, int wi
     long cells = (long)width * height;
     long blocks = (cells + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_map_obstacles, dim3(blocks), dim3(256), 0, s, map, width, height, wire, resolution, origin_x,
+    SLAM_LAUNCH(k_map_obstacles, dim3(blocks), dim3(256), 0, s, map, width, height, wire, resolution, origin_x,
                        origin_y, ox, oy, cap, count);
     return hipGetLastError();
 }
@@ -125,9 +125,9 @@ hipError_t launch_virtual_scan(const double *ox, const double *oy, int K, const 
     if (slices < 1) slices = 1;
     long total = (long)B * n;
     if (slices > 1)
-        hipLaunchKernelGGL(k_fill_u64, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
+        SLAM_LAUNCH(k_fill_u64, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<unsigned long long *>(ranges), total, bits);
-    hipLaunchKernelGGL(k_virtual_scan, dim3(slices, B), dim3(256), (size_t)n * 8, s, ox, oy, K, poses, angle_min,
+    SLAM_LAUNCH(k_virtual_scan, dim3(slices, B), dim3(256), (size_t)n * 8, s, ox, oy, K, poses, angle_min,
                        angle_increment, n, bits, reinterpret_cast<unsigned long long *>(ranges));
     return hipGetLastError();
 }
@@ -138,7 +138,7 @@ hipError_t launch_ranges64_to_points(const double *ranges, const double *cos_t, 
     long total = (long)B * n;
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_ranges64_to_points, dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, pts);
+    SLAM_LAUNCH(k_ranges64_to_points, dim3(blocks), dim3(256), 0, s, ranges, cos_t, sin_t, total, n, pts);
     return hipGetLastError();
 }
 

@@ -102,6 +102,8 @@ struct slam_grid {
     double *datamap_one = nullptr;
 };
 
+namespace slam { thread_local LaunchEvents g_launch_ev = {nullptr, nullptr}; }
+
 namespace {
 
 int arena_reserve(slam_ctx *c, Arena &a, size_t bytes)
@@ -127,23 +129,27 @@ T *carve(Arena &a, size_t count)
     return reinterpret_cast<T *>(a.base + off);
 }
 
-// RAII event bracket around one kernel family launch.
+// RAII bracket around one kernel launch of a family: arms the events the launch will carry.
 struct Timed {
     slam_ctx *c;
     int kind;
-    hipStream_t st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    Timed(slam_ctx *ctx, int k, hipStream_t on = nullptr) : c(ctx), kind(k), st(on ? on : ctx->stream)
+    Timed(slam_ctx *ctx, int k, hipStream_t = nullptr) : c(ctx), kind(k)
     {
         if (!c->timing) return;
         e0 = get();
         e1 = get();
-        if (e0 && e1) (void)hipEventRecord(e0, st);
+        if (e0 && e1) g_launch_ev = {e0, e1};
     }
     ~Timed()
     {
         if (!c->timing || !e0 || !e1) return;
-        (void)hipEventRecord(e1, st);
+        if (g_launch_ev.e0 == e0) {              // nothing was launched inside the bracket
+            g_launch_ev = {nullptr, nullptr};
+            c->pool.push_back(e0);
+            c->pool.push_back(e1);
+            return;
+        }
         c->pending.push_back({kind, e0, e1});
     }
     hipEvent_t get()

@@ -8,7 +8,28 @@
 
 #include "slam_hip.h"
 
+#include <hip/hip_ext.h>
+
 namespace slam {
+
+// Kernel timing: when the ABI layer has armed a pair of events (slam_timing_enable), the next
+// launch carries them as the dispatch's own start / stop events (hipExtLaunchKernelGGL), so
+// they bracket exactly the kernel's execution - what rocprofv3's kernel trace reports - and
+// no marker packets are put into the queue.
+struct LaunchEvents { hipEvent_t e0, e1; };
+extern thread_local LaunchEvents g_launch_ev;
+
+#define SLAM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                          \
+    do {                                                                                                              \
+        if (::slam::g_launch_ev.e0) {                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ::slam::g_launch_ev.e0, ::slam::g_launch_ev.e1, \
+                                  0, __VA_ARGS__);                                                                    \
+            ::slam::g_launch_ev.e0 = ::slam::g_launch_ev.e1 = nullptr;                                                \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                      \
+        }                                                                                                             \
+    } while (0)
+
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;            // 1024-thread workgroups

@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--grid-mode", type=int, default=1, help="1: LDS-window ray casting (default), 0: direct global atomics")
     ap.add_argument("--grid-group", type=int, default=0, help="scans per workgroup in window mode (0: automatic)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
-    ap.add_argument("--time-all-lanes", action="store_true", help="HIP events on every lane (default: lane 0 only)")
+    ap.add_argument("--time-lane0-only", action="store_true", help="HIP events on lane 0 only (default: every lane)")
     ap.add_argument("--lanes", type=int, default=4, help="contexts (stream sets) the replays alternate between")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1: map stage of a replay on a second stream, overlapping the next replay's scan matching")
@@ -188,9 +188,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # HIP events bracket every kernel of lane 0 (every len(lanes)-th replay of the timed region);
-    # bracketing all lanes costs ~5 % throughput in event markers.
-    timed_lanes = lanes if args.time_all_lanes else lanes[:1]
+    # HIP events ride on every kernel dispatch of the timed region as its start / stop events
+    # (hipExtLaunchKernelGGL inside the library): exact kernel execution times, no queue markers.
+    timed_lanes = lanes[:1] if args.time_lane0_only else lanes
     for ln in timed_lanes:
         ln.dr.ctx.timing_enable(not args.no_timing)
     t0 = time.perf_counter()
@@ -252,7 +252,7 @@ def main():
                 "valu_busy_frac_pmc": valu_busy,   # SQ_ACTIVE_INST_VALU share of the kernel's SIMD cycles (profiles/)
                 "avg_launch_ms": dom_ms / dom_n, "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms_per_step": {k: fam[k][0] / fam[k][1] for k in ms},
-                "timed": "HIP events on %d of %d lanes; durations include overlap with the other lanes' kernels"
+                "timed": "start/stop HIP events carried by every dispatch of %d of %d lanes; a duration includes the time the kernel shares the chip with the other lanes' kernels"
                          % (len(timed_lanes), len(lanes))}
     # ICP is VALU-bound, not HBM-bound.  The figure below counts the distance
     # evaluations an EXHAUSTIVE nearest-neighbour scan would make (iters * n_src * n_tar, what the

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_gpu.sh into the files kept under profiles/:
+
+  <tag>_kernel_stats_default.csv   --kernel-trace --stats of `python3 bench.py` (4 lanes)
+  <tag>_kernel_stats_1lane.csv     the same with --lanes 1 (kernels back to back)
+  <tag>_pmc_summary.txt            per-kernel, per-launch averages of every --pmc pass
+  <tag>_bench*.json                the bench lines of those runs
+  pmc_traffic.json                 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB
+                                   (gfx950: FETCH_SIZE counts wide coalesced reads at half
+                                   their bytes, MI355X_MICROARCH.md HBM section) and the VALU
+                                   busy share, read by bench.py for roofline.traffic
+
+usage: summarize_profiles.py <gpurun_out/prof_tag> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def short(name):
+    n = name.replace("void ", "")
+    n = n.split("(")[0]
+    n = n.replace("slam::", "")
+    return n.split("<")[0]
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = os.path.join(src, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for which in ("default", "1lane"):
+        f = glob.glob(os.path.join(src, "trace_" + which, "**", "*kernel_stats.csv"), recursive=True)
+        if f:
+            shutil.copy(f[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, which)))
+        b = os.path.join(src, "bench_%s_under_rocprof.json" % which)
+        if os.path.exists(b):
+            shutil.copy(b, os.path.join(dst, "%s_bench_%s_under_rocprof.json" % (tag, which)))
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    lines = ["# rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --lanes 1",
+             "# per-launch averages; FETCH_SIZE / WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes)", ""]
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        grp = open(os.path.join(d, "counters.txt")).read().strip() if os.path.exists(os.path.join(d, "counters.txt")) else d
+        lines.append("## --pmc " + grp)
+        local = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                if not k.startswith("k_"):
+                    continue
+                local[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k in sorted(local):
+            lines.append("%s %s" % (k, {c: "%.4g (n=%d)" % (sum(v) / len(v), len(v)) for c, v in sorted(local[k].items())}))
+            for c, v in local[k].items():
+                per[k][c] = v
+        lines.append("")
+    traffic = {}
+    lines.append("# derived per launch -> profiles/pmc_traffic.json")
+    for k, c in sorted(per.items()):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        avg = lambda name: sum(c[name]) / len(c[name]) if c.get(name) else None
+        fetch, write = avg("FETCH_SIZE"), avg("WRITE_SIZE")
+        hbm = (2.0 * fetch + write) * 1024.0
+        busy = None
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
+            # SQ_ACTIVE_INST_VALU counts issue slots of 4 cycles (it tracks SQ_INSTS_VALU to 2 %),
+            # summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so the
+            # kernel had (GRBM/8) x 1024 SIMD-cycles: busy = 4 A / ((G / 8) x 1024) = A / (32 G)
+            busy = avg("SQ_ACTIVE_INST_VALU") / (32.0 * avg("GRBM_GUI_ACTIVE")) if c.get("GRBM_GUI_ACTIVE") else None
+        traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kb_raw": fetch, "write_kb_raw": write,
+                      "source": "profiles/%s_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % tag,
+                      "valu_busy_frac": busy, "valu_insts_per_launch": avg("SQ_INSTS_VALU")}
+        lines.append("%s HBM %.3f MB VALU busy %s" % (k, hbm / 1e6, "n/a" if busy is None else "%.1f %%" % (100 * busy)))
+    open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    if os.path.isdir(os.path.join(root, "profiles")) and os.access(os.path.join(root, "profiles"), os.W_OK):
+        for f in os.listdir(dst):
+            shutil.copy(os.path.join(dst, f), os.path.join(root, "profiles", f))
+    print("\n".join(lines[-8:]))
+
+
+if __name__ == "__main__":
+    main()
