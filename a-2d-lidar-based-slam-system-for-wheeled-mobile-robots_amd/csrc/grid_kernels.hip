@@ -200,6 +200,7 @@ static inline int ray_block(int n)
 hipError_t launch_grid_update(const GridDev &g, const double *ox, const double *oy, const double *cx, const double *cy,
                               int B, int n, const int32_t *gob, hipStream_t s)
 {
+    if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
     SLAM_LAUNCH(k_grid_update, dim3(B), dim3(ray_block(n)), 0, s, g, ox, oy, cx, cy, n, gob);
     return hipGetLastError();
 }
@@ -208,6 +209,7 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
                                      const double *poses, int L, int n_scan, int n, const int32_t *got, hipStream_t s)
 {
     if (n_scan < 2) return hipSuccess;
+    if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
     SLAM_LAUNCH(k_grid_update_replay, dim3(n_scan - 1, L), dim3(ray_block(n)), 0, s, g, ranges, cos_t, sin_t,
                        poses, n_scan, n, got);
     return hipGetLastError();
@@ -237,6 +239,28 @@ constexpr int kSortBins = 128;        // ray-length histogram (4 cells per bin)
 constexpr int kMaxSortRays = 8192;    // rays per workgroup that can be length-sorted (u16 ids in LDS)
 constexpr int kRaysPerLane = 4;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
 
+// mapping.py:47-50 applied to the integer counters (see the header comment).
+struct OccRule {
+    int hit_levels;
+    uint32_t pass_thresh[kMaxHitLevels];
+    __host__ __device__ static OccRule of(const GridDev &g)
+    {
+        OccRule r;
+        r.hit_levels = g.hit_levels;
+        for (int k = 0; k < kMaxHitLevels; ++k) r.pass_thresh[k] = g.pass_thresh[k];
+        return r;
+    }
+    __device__ __forceinline__ uint32_t value(uint32_t p, uint32_t h) const
+    {
+        if ((p | h) == 0) return 50u;
+        if (h >= (uint32_t)hit_levels) return 100u;
+        uint32_t t = pass_thresh[0];
+#pragma unroll
+        for (int k = 1; k < kMaxHitLevels; ++k) t = (h == (uint32_t)k) ? pass_thresh[k] : t;
+        return p >= t ? 100u : 0u;
+    }
+};
+
 struct ScanConst {
     double px, py, c, s;   // ray origin (world) and heading cos / sin (replay source only)
     int pcx, pcy, cbad, pad;
@@ -253,6 +277,7 @@ struct ReplaySource {
                            // W12o/slam_ekf.py:71-77,104: the centre comes from /tf, the points from xEst)
     __device__ int scans_per_traj() const { return n_scan - 1; }
     __device__ int own_grid(int l) const { return grid_per_traj ? l : 0; }
+    bool maps_are_private() const { return grid_per_traj != 0; }
     __device__ void scan_const(int l, int k, const GridDev &g, ScanConst &sc) const
     {
         const double *pose = poses + 3 * ((size_t)l * (n_scan - 1) + k);
@@ -289,6 +314,7 @@ struct ExplicitSource {
     int B, n;
     __device__ int scans_per_traj() const { return B; }
     __device__ int own_grid(int) const { return 0; }
+    bool maps_are_private() const { return false; }
     __device__ void scan_const(int, int k, const GridDev &g, ScanConst &sc) const
     {
         sc.px = cx[k]; sc.py = cy[k]; sc.c = 1.0; sc.s = 0.0;
@@ -374,7 +400,8 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
 }
 
 template <class Src>
-__global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got)
+__global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got,
+                                                          int exclusive)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [kWinMaxGroup]
@@ -391,6 +418,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
     const int n = src.n, nrays = cnt * n;
 
+    // exclusive owner of the map + live pmap + rows that are a multiple of 4 cells: the flush is a
+    // plain vectorised read-modify-write of the touched rectangle that also re-thresholds pmap
+    const bool fused = exclusive && g.pmap_live && (g.yw & 3) == 0 && (((size_t)gi * g.xw * g.yw) & 3) == 0;
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
     if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; }
     const bool sorted = nrays <= kMaxSortRays;
@@ -422,10 +452,12 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         int W = 0, H = 0, covers = 1;
         if (x0 <= x1 && y0 <= y1) {
+            if (fused) y0 &= ~3;                                      // quads of the fused flush line up with the window's dwords
             W = x1 - x0 + 1; H = y1 - y0 + 1;
             if ((long)W * ((H + 1) & ~1) > kWinCells) {               // keep a sub-rectangle around the first origin
                 int Hd = min(H, 192), Wd = min(W, kWinCells / Hd);
                 int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
+                if (fused) cy0 &= ~3;
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
                 covers = 0;
             }
@@ -465,7 +497,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // every workgroup flushes the same part of the map: start each one at a different row so
     // that concurrent flushes do not queue on the same addresses
     const int rot = W > 0 ? (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)W) : 0;
-    for (int rr = wave; rr < W; rr += nwaves) {
+    for (int rr = wave; rr < (fused ? 0 : W); rr += nwaves) {
         const int row = rr + rot < W ? rr + rot : rr + rot - W;
         size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
         for (int d = lane; d < Hp2; d += kWave) {
@@ -482,6 +514,66 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     if (lane == 0) {
         if (tot) atomicAdd(g.visits, (unsigned long long)tot);
         if (anybad) atomicOr(g.status, anybad);
+    }
+    // Live pmap: this workgroup is the only writer of its map during the launch, so once its own
+    // atomics (hits, out-of-window passes) have landed it finishes every cell its rays could have
+    // touched - the bounding box of pass 1, clamped to the map - in one sweep: add the window's
+    // pass counts with plain 16-byte read-modify-writes (no flush atomics) and re-threshold pmap,
+    // the finalize pass restricted to what changed.
+    if (exclusive && g.pmap_live) {
+        __threadfence();
+        __syncthreads();
+        const int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
+        if (x0 <= x1 && y0 <= y1) {
+            const OccRule rule = OccRule::of(g);
+            int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
+            // plain loads are safe: the counters were only touched by this workgroup's atomics (done,
+            // fenced) and nothing of this map has been read into this CU's L1 during the launch
+            if (fused) {
+                const int ya = y0 & ~3, qrow = ((y1 | 3) + 1 - ya) >> 2, rows = x1 - x0 + 1;
+                const int total = rows * qrow;
+                // (pm is a char pointer and may alias anything for the compiler: the loads of a batch
+                // are issued before its stores by hand)
+                constexpr int kBatch = 4;
+                for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
+                    uint4 p[kBatch], h[kBatch];
+                    size_t at[kBatch];
+                    bool add[kBatch];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        int q = min(q0 + u * (int)blockDim.x, total - 1);
+                        int r = q / qrow, c = q - r * qrow;
+                        int x = x0 + r, y = ya + 4 * c;
+                        at[u] = (size_t)x * g.yw + y;
+                        p[u] = *reinterpret_cast<const uint4 *>(pass + at[u]);
+                        h[u] = *reinterpret_cast<const uint4 *>(hit + at[u]);
+                        unsigned wx = (unsigned)(x - wx0), wy = (unsigned)(y - wy0);   // wy is a multiple of 4 when inside
+                        unsigned d0 = 0, d1 = 0;
+                        if (wx < (unsigned)W && wy < (unsigned)H) {
+                            unsigned di = wx * Hp2 + (wy >> 1);
+                            d0 = win[di];
+                            d1 = (wy >> 1) + 1 < (unsigned)Hp2 ? win[di + 1] : 0u;
+                        }
+                        add[u] = (d0 | d1) != 0;
+                        p[u].x += d0 & 0xffffu; p[u].y += d0 >> 16;
+                        p[u].z += d1 & 0xffffu; p[u].w += d1 >> 16;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        if (q0 + u * (int)blockDim.x >= total) continue;
+                        if (add[u]) *reinterpret_cast<uint4 *>(pass + at[u]) = p[u];
+                        uint32_t out = rule.value(p[u].x, h[u].x) | rule.value(p[u].y, h[u].y) << 8 |
+                                       rule.value(p[u].z, h[u].z) << 16 | rule.value(p[u].w, h[u].w) << 24;
+                        *reinterpret_cast<uint32_t *>(pm + at[u]) = out;
+                    }
+                }
+            } else {
+                for (int x = x0 + wave; x <= x1; x += nwaves) {
+                    size_t rowb = (size_t)x * g.yw;
+                    for (int y = y0 + lane; y <= y1; y += kWave) pm[rowb + y] = (int8_t)rule.value(pass[rowb + y], hit[rowb + y]);
+                }
+            }
+        }
     }
 }
 
@@ -503,7 +595,15 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     long want = (rays + kRaysPerLane - 1) / kRaysPerLane;
     int threads = want >= 1024 ? 1024 : (int)(((want + kWave - 1) / kWave) * kWave);
     if (threads < 128) threads = 128;
-    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got);
+    // one workgroup per map and no other writer: single stream (L == 1) or one map per stream
+    const int exclusive = g.pmap_live && groups == 1 && !got && (L == 1 || src.maps_are_private());
+    if (g.pmap_live && !exclusive && g.live_dirty) *g.live_dirty = true;
+    // the window takes most of a CU's LDS, so a CU runs one or two workgroups: the flush / the
+    // exclusive sweep (a streaming pass over the touched rectangle) need lanes for memory
+    // operations in flight even when there are few rays (measured on 10 000 single-scan groups:
+    // 2.88 ms with 128 threads, 2.05 ms with 512)
+    if (threads < 512) threads = 512;
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got, exclusive);
     return hipGetLastError();
 }
 
@@ -556,21 +656,6 @@ hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const
     return launch_win(g, src, 1, S, n, G, nullptr, s);
 }
 
-// mapping.py:47-50 applied to the integer counters (see the header comment).
-struct OccRule {
-    int hit_levels;
-    uint32_t pass_thresh[kMaxHitLevels];
-    __device__ __forceinline__ uint32_t value(uint32_t p, uint32_t h) const
-    {
-        if ((p | h) == 0) return 50u;
-        if (h >= (uint32_t)hit_levels) return 100u;
-        uint32_t t = pass_thresh[0];
-#pragma unroll
-        for (int k = 1; k < kMaxHitLevels; ++k) t = (h == (uint32_t)k) ? pass_thresh[k] : t;
-        return p >= t ? 100u : 0u;
-    }
-};
-
 __global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,
                                                        size_t cells, OccRule rule, int8_t *__restrict__ pmap)
 {
@@ -594,9 +679,7 @@ hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pm
     size_t blocks = (cells / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    OccRule rule;
-    rule.hit_levels = g.hit_levels;
-    for (int k = 0; k < kMaxHitLevels; ++k) rule.pass_thresh[k] = g.pass_thresh[k];
+    OccRule rule = OccRule::of(g);
     SLAM_LAUNCH(k_grid_finalize, dim3(blocks), dim3(256), 0, s, g.pass + per * g0, g.hit + per * g0, cells, rule, pmap);
     return hipGetLastError();
 }

@@ -100,6 +100,8 @@ struct slam_grid {
     size_t state_bytes = 0;        // pass[] + hit[] + visit counter, one allocation
     int8_t *pmap_one = nullptr;    // [xw][yw] read-back staging
     double *datamap_one = nullptr;
+    int8_t *pmap_live = nullptr;   // [G][xw][yw], slam_grid_live_pmap
+    bool live_dirty = false;       // pmap_live is behind the counters
 };
 
 namespace slam { thread_local LaunchEvents g_launch_ev = {nullptr, nullptr}; }
@@ -609,6 +611,8 @@ int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double of
         return fail(SLAM_ERR_NOMEM, "grid allocation (%zu cells): %s", cells, hipGetErrorString(e));
     }
     g->d.visits = g->visits;
+    g->d.pmap_live = nullptr;
+    g->d.live_dirty = &g->live_dirty;
     *out = g;
     return slam_grid_reset(c, g);
 }
@@ -621,6 +625,7 @@ int slam_grid_destroy(slam_ctx *c, slam_grid *g)
         (void)hipStreamSynchronize(c->stream);
         if (c->gstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamSynchronize(c->gstream); }
     }
+    if (g->pmap_live) (void)hipFree(g->pmap_live);
     if (g->d.pass) (void)hipFree(g->d.pass);   // also holds hit[] and the visit counter
     if (g->pmap_one) (void)hipFree(g->pmap_one);
     if (g->datamap_one) (void)hipFree(g->datamap_one);
@@ -637,6 +642,10 @@ int slam_grid_reset(slam_ctx *c, slam_grid *g)
         c->mgrid = false;
     }
     HIPCHK(hipMemsetAsync(g->d.pass, 0, g->state_bytes, gs(c)));
+    if (g->pmap_live) {
+        HIPCHK(hipMemsetAsync(g->pmap_live, 50, (size_t)g->d.G * g->d.xw * g->d.yw, gs(c)));
+        g->live_dirty = false;
+    }
     if (c->pipeline) c->gdirty = true;
     return SLAM_OK;
 }
@@ -712,11 +721,46 @@ int slam_grid_update_scans(slam_ctx *c, slam_grid *g, const float *ranges, const
     return check_status_sync(c);
 }
 
+static int refresh_live(slam_ctx *c, slam_grid *g, hipStream_t st)
+{
+    if (!g->pmap_live || !g->live_dirty) return SLAM_OK;
+    Timed t(c, SLAM_K_FINALIZE, st);
+    HIPCHK(launch_grid_finalize(g->d, 0, g->d.G, g->pmap_live, st));
+    g->live_dirty = false;
+    return SLAM_OK;
+}
+
+int slam_grid_live_pmap(slam_ctx *c, slam_grid *g, int8_t **pmap_dev_out)
+{
+    TRY(use(c));
+    REQUIRE(g && pmap_dev_out, "null pointer");
+    TRY(grid_on_main(c));
+    if (!g->pmap_live) {
+        size_t bytes = (size_t)g->d.G * g->d.xw * g->d.yw;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->pmap_live), align_up(bytes));
+        if (e != hipSuccess) {
+            g->pmap_live = nullptr;
+            return fail(SLAM_ERR_NOMEM, "live pmap (%zu bytes): %s", bytes, hipGetErrorString(e));
+        }
+        g->d.pmap_live = g->pmap_live;
+        g->live_dirty = true;
+        TRY(refresh_live(c, g, c->stream));
+    }
+    *pmap_dev_out = g->pmap_live;
+    return SLAM_OK;
+}
+
 int slam_grid_finalize_dev(slam_ctx *c, slam_grid *g, int8_t *pmap_dev)
 {
     TRY(use(c));
     REQUIRE(g && pmap_dev, "null pointer");
     TRY(fork_to_grid(c));          // pmap_dev may still be in use by work on the main stream
+    if (g->pmap_live) {            // kept current by the ray casts; refresh only if something bypassed that
+        TRY(refresh_live(c, g, gs(c)));
+        if (pmap_dev != g->pmap_live)
+            HIPCHK(hipMemcpyAsync(pmap_dev, g->pmap_live, (size_t)g->d.G * g->d.xw * g->d.yw, hipMemcpyDeviceToDevice, gs(c)));
+        return SLAM_OK;
+    }
     Timed t(c, SLAM_K_FINALIZE, gs(c));
     HIPCHK(launch_grid_finalize(g->d, 0, g->d.G, pmap_dev, gs(c)));
     return SLAM_OK;
@@ -729,7 +773,10 @@ int slam_grid_read(slam_ctx *c, slam_grid *g, int gi, int8_t *pmap, double *data
     REQUIRE(g, "null grid");
     REQUIRE(gi >= 0 && gi < g->d.G, "grid index out of range");
     size_t per = (size_t)g->d.xw * g->d.yw;
-    if (pmap) {
+    if (pmap && g->pmap_live) {
+        TRY(refresh_live(c, g, c->stream));
+        D2H(pmap, g->pmap_live + per * gi, per);
+    } else if (pmap) {
         {
             Timed t(c, SLAM_K_FINALIZE);
             HIPCHK(launch_grid_finalize(g->d, gi, 1, g->pmap_one, c->stream));

@@ -80,6 +80,11 @@ struct GridDev {
     // passes is occupied iff h >= hit_levels or p >= pass_thresh[h].
     int hit_levels;                // 1 for the reference's +20 (one hit occupies), 3 for the online variant's +4
     uint32_t pass_thresh[kMaxHitLevels];
+    // Live pmap (slam_grid_live_pmap): [G][xw][yw] int8 kept current by ray casts that own their
+    // map exclusively (one workgroup per map); any other update sets *live_dirty (host flag) and
+    // the next finalize / read refreshes it with a full pass.
+    int8_t *pmap_live;
+    bool *live_dirty;
     double free_inc, hit_inc;
 };
 

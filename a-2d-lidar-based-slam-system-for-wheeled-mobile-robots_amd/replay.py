@@ -130,6 +130,13 @@ class DeviceGrid:
     def reset(self):
         _abi.check(_abi.lib().slam_grid_reset(self._ctx.handle, self._h))
 
+    def live_pmap(self):
+        """Keep ``pmap`` [G, xw, yw] int8 resident and current on the device
+        (``slam_grid_live_pmap``); returns its device address."""
+        p = C.c_void_p()
+        _abi.check(_abi.lib().slam_grid_live_pmap(self._ctx.handle, self._h, C.byref(p)))
+        return int(p.value)
+
     def update_host(self, ox, oy, cx, cy, grid_of_batch=None):
         ox = np.ascontiguousarray(np.asarray(ox, dtype=np.float64))
         oy = np.ascontiguousarray(np.asarray(oy, dtype=np.float64))

@@ -170,6 +170,13 @@ int slam_grid_update_scans_dev(slam_ctx *ctx, slam_grid *grid, const float *rang
  * = free_inc*pass + hit_inc*hit; pass, hit [xw][yw] uint32. */
 int slam_grid_read(slam_ctx *ctx, slam_grid *grid, int g, int8_t *pmap, double *datamap, uint32_t *pass,
                    uint32_t *hit);
+/* Keep pmap [G][xw][yw] int8 resident and current on the device and return its address.
+ * Ray casts that are the only writer of their map in a launch (one scan group per map: the
+ * per-particle maps of slam_particles, Mapping.update of one scan) re-threshold just the cells
+ * they could have touched, so no finalize pass over the whole map is needed afterwards; any
+ * other update marks it stale and the next finalize / read refreshes it with a full pass.
+ * slam_grid_finalize_dev(pmap_dev == that address) then costs nothing when it is current. */
+int slam_grid_live_pmap(slam_ctx *ctx, slam_grid *grid, int8_t **pmap_dev_out);
 /* Device-side finalize of all G maps into pmap_dev [G][xw][yw] int8 (no synchronise). */
 int slam_grid_finalize_dev(slam_ctx *ctx, slam_grid *grid, int8_t *pmap_dev);
 /* Replaces the data layout of SLAM_EKF.publishMap (W12m/slam_ekf.py:270-271):

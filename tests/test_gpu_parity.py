@@ -432,6 +432,45 @@ def test_full_size_replay(slam, syn):
     torch.cuda.synchronize()
 
 
+def test_live_pmap_matches_finalize(slam, syn):
+    """slam_grid_live_pmap: ray casts that own their map keep pmap current cell for cell (per-
+    particle maps, single-scan Mapping.update); shared-map updates mark it stale and the next
+    read refreshes it.  Always equal to the full finalize of the counters."""
+    rep = syn.make_replay(2, 360, seed=2, stride=5)
+    P = 24
+    priors = slam.prior_matrices(syn.particle_priors(P, seed=2))
+    for live in (False, True):
+        grid = slam.DeviceGrid.metric(P, 400, 400, 0.05)
+        if live:
+            assert grid.live_pmap() != 0
+        for _ in range(3):                                   # maps persist: three filter steps
+            slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, priors, np.zeros((P, 3)), grid=grid)
+        maps = [grid.read(g, want=("pmap", "pass", "hit")) for g in range(P)]
+        if not live:
+            want = maps
+    for a, b in zip(maps, want):
+        assert np.array_equal(a["pass"], b["pass"]) and np.array_equal(a["hit"], b["hit"]) and np.array_equal(a["pmap"], b["pmap"])
+    assert any(np.any(m["pmap"] == 100) for m in maps) and any(np.any(m["pmap"] == 0) for m in maps)
+    # single map: one scan per call is exclusive (live), a 40-scan replay is not (stale -> refreshed)
+    rep = syn.make_replay(40, 360, seed=6, stride=5)
+    outs = []
+    for live in (False, True):
+        grid = slam.DeviceGrid.metric(1, 400, 400, 0.05)
+        if live:
+            grid.live_pmap()
+        slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid)
+        r1 = grid.read(0, want=("pmap",))["pmap"].copy()
+        ox = np.linspace(-3, 3, 50)[None]
+        grid.update_host(ox, 0.3 * ox + 1.0, np.array([0.2]), np.array([-0.1]))
+        r2 = grid.read(0, want=("pmap",))["pmap"].copy()
+        grid.reset()
+        r3 = grid.read(0, want=("pmap",))["pmap"].copy()
+        outs.append((r1, r2, r3))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.all(outs[1][2] == 50) and not np.array_equal(outs[1][0], outs[1][1])
+
+
 def test_pipelined_map_stage_is_bit_identical(slam, syn):
     """"pipeline" option: the map stage on a second stream (overlapping the next replay's scan
     matching) gives the same bits as the serial order, with alternating AND with reused pose
