@@ -7,7 +7,8 @@ zjwzcx/A-2D-LiDAR-based-SLAM-System-for-Wheeled-Mobile-Robots:
     ICP        process / findNearest / getTransform / laserToNumpy / laserCallback / publishResult
     Mapping    update -> pmap
     bresenham  (start, end).path
-    SLAM_EKF   laserCallback glue (scan matching + map building; no EKF, no landmarks)
+    SLAM_EKF   laserCallback glue (scan matching + map building); landmarks=True: the whole W12
+               node with Extraction and the landmark EKF on the host
     Localization  updateMap / laserEstimation / calc_map_observation (scan-to-map, W9)
 
 plus the batched forms used by bench.py (``replay``) and the multi-GPU sharding helper
@@ -17,6 +18,8 @@ libslamhip.so or the GPU is missing (there is no CPU implementation in the produ
 from . import _abi, param, synthetic
 from ._abi import Context, LibraryMissing, SlamError, default_context
 from .bresenham import bresenham, rasterize
+from .ekf_lm import EKF
+from .extraction import Extraction, LandMarkSet
 from .icp import ICP, scan_to_pc
 from .localization import Localization
 from .mapping import Mapping
@@ -24,6 +27,6 @@ from .replay import DeviceGrid, DeviceReplay, icp_batch_host, particles_host, pr
 from .slam_ekf import SLAM_EKF
 from .synthetic import LaserScan
 
-__all__ = ["ICP", "Mapping", "Localization", "bresenham", "rasterize", "SLAM_EKF", "LaserScan", "Context", "default_context",
+__all__ = ["ICP", "Mapping", "Localization", "EKF", "Extraction", "LandMarkSet", "bresenham", "rasterize", "SLAM_EKF", "LaserScan", "Context", "default_context",
            "DeviceGrid", "DeviceReplay", "replay_host", "icp_batch_host", "particles_host", "prior_matrices", "scan_to_pc", "SlamError",
            "LibraryMissing", "param", "synthetic"]

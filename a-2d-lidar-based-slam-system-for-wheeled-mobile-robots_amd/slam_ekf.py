@@ -5,10 +5,12 @@ Mirrors the glue of W12m/slam_ekf.py that sits on the hot path (a
 publishing), ``calc_odometry`` :109-113, ``laserToNumpy`` :115-123, ``T2u`` :125-128,
 ``u2T`` :130-137 and the OccupancyGrid layout of ``publishMap`` :252-275.
 
-Out of scope and absent here: the landmark EKF
-(``ekf.estimate`` :86) and landmark extraction (:79-82).  The reference feeds the EKF
-estimate ``xEst`` to the mapper; here ``xEst`` is the dead-reckoned ICP pose
-(icp.py:185-190), which is what the EKF's prediction step integrates.
+Two modes.  ``SLAM_EKF()`` is the hot path alone: ``xEst`` is the dead-reckoned ICP pose
+(icp.py:185-190), which is what the EKF's prediction step integrates, and one processed scan
+costs ONE library call.  ``SLAM_EKF(landmarks=True)`` is the whole W12 node:
+landmark extraction (:79, ``extraction.py``) and the landmark EKF (:86, ``ekf_lm.py``) run on
+the host between the device-side scan matching and map building, and the map is cast from the
+filter's ``xEst`` exactly as :88-90 do.
 
 One processed scan costs ONE library call: ``slam_replay`` over the (previous, current)
 scan pair runs polar->Cartesian, the whole ICP solve, the pose composition, the
@@ -22,6 +24,8 @@ import math
 import numpy as np
 
 from . import _abi
+from .ekf_lm import EKF
+from .extraction import Extraction
 from .icp import ICP, scan_to_pc
 from .mapping import Mapping
 from .param import get_param
@@ -31,12 +35,15 @@ STATE_SIZE = 3
 
 
 class SLAM_EKF:  # noqa: N801 (the reference's class name)
-    def __init__(self, context=None, online=False):
+    def __init__(self, context=None, online=False, landmarks=False):
         """``online=True`` is the node of w12-mapping-online: +4 end-point evidence
         (W12o/mapping.py:46), every 6th message (W12o/slam_ekf.py:81) and ray origins taken
         from the last /tf message (``tf_callback``, :71-77,104) instead of xEst."""
         self._ctx = context or _abi.default_context()
         self.online = bool(online)
+        self.landmarks = bool(landmarks)
+        self.ekf = EKF() if self.landmarks else None
+        self.extraction = Extraction() if self.landmarks else None
         self.x_online = 0
         self.y_online = 0
         self.z_online = 0
@@ -96,6 +103,8 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
         self.laser_count = 0
         ranges = np.ascontiguousarray(np.asarray(msg.ranges, dtype=np.float32))
         self._angles = (msg.angle_min, msg.angle_max)
+        if self.landmarks:
+            return self._landmark_callback(msg, ranges)
         if self.isFirstScan:                                       # :74-78
             self.isFirstScan = False
             self._prev_ranges = ranges
@@ -128,6 +137,45 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
                                              _abi.ptr(self.mapping.datamap), None, None))
         self.mapping.pmap[...] = self.mapping._p8
         self.publishMap(self.mapping.pmap)                         # :91
+
+    def _landmark_callback(self, msg, ranges):
+        """slam_ekf.py:73-95 in full: extraction -> odometry -> EKF -> map from xEst."""
+        np_msg = self.laserToNumpy(msg)                            # :73
+        if self.isFirstScan:                                       # :74-78
+            self.isFirstScan = False
+            self._tar_cloud = np_msg
+            self._prev_ranges = ranges
+            return
+        lm = self.extraction.process(np_msg)                       # :79
+        if lm is None:                                             # :80-82: nothing else happens, not even
+            return                                                 # the odometry target moves on
+        self._cur_ranges = ranges
+        u = self.calc_odometry(np_msg)                             # :84
+        self._prev_ranges = ranges
+        z = self.observation(lm)                                   # :85
+        self.xEst, self.PEst = self.ekf.estimate(self.xEst, self.PEst, z, u)   # :86
+        self.last_u, self.last_landmarks = u, lm
+        n = ranges.shape[0]
+        ct, st = _abi.trig_tables(msg.angle_min, msg.angle_max, n)
+        pose = np.ascontiguousarray(self.xEst[:3, 0].reshape(1, 3))
+        centre = None
+        if self.online:
+            centre = np.array([[float(self.x_online), float(self.y_online)]])
+        _abi.check(_abi.lib().slam_grid_update_scans(self._ctx.handle, self.mapping._grid, _abi.ptr(ranges), _abi.ptr(ct),
+                                                     _abi.ptr(st), _abi.ptr(pose), _abi.ptr(centre), 1, n))   # :88-90
+        _abi.check(_abi.lib().slam_grid_read(self._ctx.handle, self.mapping._grid, 0, _abi.ptr(self.mapping._p8),
+                                             _abi.ptr(self.mapping.datamap), None, None))
+        self.mapping.pmap[...] = self.mapping._p8
+        self.publishMap(self.mapping.pmap)                         # :91
+
+    def observation(self, lm):
+        """slam_ekf.py:96-106: landmarks (sensor frame) -> rows (range, bearing, index)."""
+        z = np.zeros((0, 3))
+        for i in range(len(lm.id)):
+            dx, dy = lm.position_x[i], lm.position_y[i]
+            zi = np.array([math.hypot(dx, dy), self.ekf.pi_2_pi(math.atan2(dy, dx)), i])
+            z = np.vstack((z, zi))
+        return z
 
     def calc_odometry(self, np_msg):
         """slam_ekf.py:109-113 on explicit clouds (3xN): returns u = [tx, ty, dyaw]^T and

@@ -10,6 +10,8 @@ seeded synthetic inputs, and only the inputs and outputs are written out.
   O2  W12m/mapping.py     loaded as-is with empty stub modules for rospy / nav_msgs.
   O3  W12f/icp-fhb.py     loaded as-is with ``np.int = int`` (cross-check only; its
                           reflection branch indexes Vt[2,:] and is never exercised).
+  O5  W12m/ekf_lm.py, extraction.py, slam_ekf.py (whole node)   as O4, plus the Python-2
+                          integer divisions ``(len(x)-3)/2`` kept integer (``//``), in memory.
   O4  W12m/icp.py         Python-2 print statements rewritten IN MEMORY by lib2to3's
                           fix_print, then exec'd with stubs for rospy / tf / *_msgs.
       W12m/slam_ekf.py    same treatment, used only for its glue methods
@@ -99,9 +101,15 @@ def _load_asis(name, path):
     return m
 
 
-def _load_py2(name, path):
+def _load_py2(name, path, int_div=()):
+    """``int_div``: expressions whose ``/`` is an integer division under Python 2 (int / int) and
+    must stay one (``//``) for the module to mean the same under Python 3 - rewritten in memory,
+    like the print statements."""
     from lib2to3.refactor import RefactoringTool
     text = open(path).read()
+    for expr in int_div:
+        assert expr in text, expr
+        text = text.replace(expr, expr.replace("/", "//"))
     tree = RefactoringTool(["lib2to3.fixes.fix_print"]).refactor_string(text + "\n", path)
     m = types.ModuleType(name)
     m.__file__ = path
@@ -119,6 +127,13 @@ def load_reference():
     ref.icp_fhb = _load_asis("icp_fhb", os.path.join(W12F, "icp-fhb.py"))           # O3
     ref.icp = _load_py2("icp", os.path.join(W12M, "icp.py"))                        # O4
     ref.slam_ekf = _load_py2("slam_ekf", os.path.join(W12M, "slam_ekf.py"))
+    # O5: the W12 node in full: the real landmark EKF and extraction instead of the
+    # stubs, and a second copy of slam_ekf.py bound to them
+    stubs = {k: sys.modules[k] for k in ("ekf_lm", "extraction")}
+    ref.ekf_lm = _load_py2("ekf_lm", os.path.join(W12M, "ekf_lm.py"), int_div=("-3)/2",))
+    ref.extraction = _load_py2("extraction", os.path.join(W12M, "extraction.py"))
+    ref.slam_ekf_full = _load_py2("slam_ekf_full", os.path.join(W12M, "slam_ekf.py"), int_div=("-STATE_SIZE)/2",))
+    sys.modules.update(stubs)
     ref.mapping_online = _load_asis("mapping_online", os.path.join(W12O, "mapping.py"))   # O2, the +4 variant
     ref.localization = _load_py2("localization", os.path.join(W9, "localization.py"))   # imports the O4 `icp`
     return ref
@@ -507,14 +522,104 @@ def gen_g6(ref, out_dir):
     save(out_dir, "g6_mapping_online.npz", **arrays)
 
 
+def landmark_world():
+    """Room with four thin poles (r = 0.08 m, > 1.2 m from every wall): what Extraction accepts as
+    landmarks (cluster extent < 0.3 m, separated from the background by > 1 m gaps)."""
+    return syn.World(5.0, 4.0, ((1.5, 1.0), (-1.8, -0.9), (0.5, -2.0), (-2.5, 1.5)), 0.08)
+
+
+def gen_g7(ref, out_dir):
+    """The rest of the W12 node: Extraction.process, EKF.estimate and the whole
+    SLAM_EKF.laserCallback (extraction -> ICP odometry -> landmark EKF -> map from xEst)."""
+    arrays = {}
+    world = landmark_world()
+    rng = np.random.default_rng(77)
+    # (a) extraction on 12 scans from seeded poses
+    poses = np.stack([rng.uniform(-1.0, 1.0, 12), rng.uniform(-0.8, 0.8, 12), rng.uniform(-np.pi, np.pi, 12)], axis=1)
+    ranges = syn.scans_from_poses(world, poses, 360, 71)
+    ex = ref.extraction.Extraction()
+    node = object.__new__(ref.slam_ekf_full.SLAM_EKF)
+    node.ekf = ref.ekf_lm.EKF()
+    ids, px, py, offs, zs = [], [], [], [0], []
+    for k in range(12):
+        pc = node.laserToNumpy(syn.LaserScan(ranges=tuple(float(v) for v in ranges[k])))
+        with quiet():
+            lm = ex.process(pc)
+        if lm is not None:
+            ids += list(lm.id); px += list(lm.position_x); py += list(lm.position_y)
+            zs.append(node.observation(lm))
+        offs.append(len(ids))
+    # two scans with no landmark at all (empty room) -> None
+    empty = syn.scans_from_poses(syn.World(5.0, 4.0, (), 0.0), poses[:2], 360, 72)
+    none_flags = []
+    for k in range(2):
+        with quiet():
+            none_flags.append(ex.process(node.laserToNumpy(syn.LaserScan(ranges=tuple(float(v) for v in empty[k])))) is None)
+    arrays.update(ext_ranges=ranges, ext_id=np.array(ids), ext_x=np.array(px), ext_y=np.array(py), ext_offsets=np.array(offs),
+                  ext_z=np.concatenate(zs), ext_empty_ranges=empty, ext_empty_is_none=np.array(none_flags))
+    # (b) EKF.estimate over a sequence: robot creeps forward, sees 2-4 landmarks with noise
+    ekf = ref.ekf_lm.EKF()
+    lms = np.array(world.pillars)
+    xE, PE = np.zeros((3, 1)), np.eye(3)
+    true = np.zeros(3)
+    xs, Ps, sizes, z_all, z_off, us = [], [], [], [], [0], []
+    for t in range(14):
+        u = np.array([[0.05 + rng.normal(0, 0.005)], [rng.normal(0, 0.005)], [0.02 + rng.normal(0, 0.002)]])
+        true = np.array([true[0] + np.cos(true[2]) * u[0, 0] - np.sin(true[2]) * u[1, 0],
+                         true[1] + np.sin(true[2]) * u[0, 0] + np.cos(true[2]) * u[1, 0], true[2] + u[2, 0]])
+        seen = [j for j in range(4) if (t + j) % 5 != 0][: 2 + t % 3] if t else [0]   # first call: one landmark only
+        z = np.zeros((0, 3))
+        for i, j in enumerate(seen):
+            d = lms[j] - true[:2]
+            z = np.vstack((z, [np.hypot(d[0], d[1]) + rng.normal(0, 0.01),
+                               ekf.pi_2_pi(np.arctan2(d[1], d[0]) - true[2] + rng.normal(0, 0.005)), i]))
+        try:
+            with quiet():
+                xE, PE = ekf.estimate(xE, PE, z, u)
+            ok = 1
+        except ValueError:       # two NEW landmarks in one call: the reference's hstack fails (ekf_lm.py:38)
+            ok = 0
+        us.append(u[:, 0]); z_all.append(z); z_off.append(z_off[-1] + len(z))
+        pad = np.full(11, np.nan); pad[:len(xE)] = xE[:, 0]
+        Pp = np.full((11, 11), np.nan); Pp[:len(xE), :len(xE)] = PE
+        xs.append(pad); Ps.append(Pp); sizes.append(len(xE) if ok else -len(xE))
+        if not ok:
+            break
+    arrays.update(ekf_u=np.array(us), ekf_z=np.concatenate(z_all), ekf_z_offsets=np.array(z_off), ekf_x=np.array(xs),
+                  ekf_P=np.array(Ps), ekf_sizes=np.array(sizes))
+    # (c) the whole node on a 66-message stream (11 processed scans)
+    sys.modules["rospy"].get_param = lambda name, default=None: PARAMS.get(name, default)
+    traj = np.stack([0.3 + 0.004 * np.arange(66), -0.2 + 0.002 * np.arange(66), 0.1 + 0.003 * np.arange(66)], axis=1)
+    stream = syn.scans_from_poses(world, traj, 360, 73)
+    with quiet():
+        full = ref.slam_ekf_full.SLAM_EKF()
+    for name in ("publishMap", "publishLandMark", "publishResult"):
+        setattr(full, name, lambda *a, **k: None)
+    # u2T builds np.array([[cos, -sin, dx], ...]) with dx a 1-element array: an object matrix in the
+    # NumPy of the reference's day, an error under NumPy 2 - hand it the same three numbers as floats
+    u2T = full.u2T
+    full.u2T = lambda u: u2T([float(u[0]), float(u[1]), float(u[2])])
+    states, nlm, steps = [], [], []
+    for k in range(66):
+        before = full.xEst.copy()
+        with quiet():
+            full.laserCallback(syn.LaserScan(ranges=tuple(float(v) for v in stream[k])))
+        if full.xEst.shape != before.shape or not np.array_equal(full.xEst, before):
+            steps.append(k); states.append(full.xEst[:3, 0].copy()); nlm.append((len(full.xEst) - 3) // 2)
+    arrays.update(node_ranges=stream, node_steps=np.array(steps), node_xest=np.array(states), node_nlm=np.array(nlm),
+                  node_pmap=np.array(full.mapping.pmap, dtype=np.int8), node_final_x=full.xEst[:, 0].copy(),
+                  node_final_P=np.array(full.PEst))
+    save(out_dir, "g7_w12_node.npz", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference()
-    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6)):
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6), ("g7", gen_g7)):
         if name in args.only.split(","):
             t0 = time.time()
             fn(ref, args.out)
