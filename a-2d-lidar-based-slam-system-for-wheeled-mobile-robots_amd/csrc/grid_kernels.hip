@@ -656,6 +656,248 @@ hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const
     return launch_win(g, src, 1, S, n, G, nullptr, s);
 }
 
+// ---------------------------------------------------------------------------------
+// Tiled ray casting for maps far larger than one LDS window (DESIGN.md "K4 tiles"; the
+// 2000x2000 @ 0.02 m map of BASELINE.json configs[4], where a scan's rays cover ~800 k cells
+// and the window kernel fell back to scattered global atomics for most of them).
+//
+// The float-error Bresenham walk (bresenham.py:45-55) cannot be entered in the middle: its
+// state is a rounded running sum.  So every ray is walked ONCE (k_ray_bits), touching no map
+// cell, and the walk is recorded as one bit per step - "y advanced after this step" - plus a
+// running count of set bits per 32-step word.  With those, the cell of step k is
+// (x0 + k, y0 + ystep * popcount(bits[0..k))) for any k, so a second kernel (k_tile_cast) can
+// give every (map tile, scan group) pair its own workgroup: it enters each ray where it
+// crosses the tile, accumulates the tile's pass counts in LDS exactly like the window kernel,
+// and flushes the non-zero cells row by row.  The cells visited are the reference's by
+// construction (same walk, recorded instead of applied).  Hits (one per ray) and the visit
+// counter are handled by the first kernel; rays of 2048 steps or more take the direct path
+// there.
+// ---------------------------------------------------------------------------------
+constexpr int kTileSteps = 2048;                 // rays with dx < kTileSteps are recorded
+constexpr int kTileWords = kTileSteps / 32;
+constexpr int kTileSide = 192;                   // 192 x 192 16-bit cells = the 72 KiB window
+
+struct RayRec {
+    int x0, y0, dx, yend;                        // walk coordinates; yend = y of the cell at step dx
+    uint32_t flags;                              // 1: steep, 2: reversed (path runs end -> start), 4: ystep > 0, 8: valid
+    int pad[3];
+};
+
+struct TileScratch {
+    RayRec *recs;                                // [rays]
+    uint32_t *bits;                              // [rays][kTileWords]
+    unsigned short *prefix;                      // [rays][kTileWords]: set bits before each word
+    int *gbox;                                   // [groups][4]: map-space bounding box of a group's recorded rays
+};
+
+__global__ void __launch_bounds__(256) k_tile_init(int *gbox, int groups)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < groups) { gbox[4 * i] = gbox[4 * i + 1] = INT_MAX; gbox[4 * i + 2] = gbox[4 * i + 3] = INT_MIN; }
+}
+
+// Pass A: block (scan, stream) walks the scan's rays once.
+template <class Src>
+__global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratch ts, int group_size)
+{
+    __shared__ ScanConst sc;
+    __shared__ int box[4];
+    const int s = blockIdx.x, l = blockIdx.y, n = src.n;
+    const int scans = src.scans_per_traj();
+    const int groups_per_traj = (scans + group_size - 1) / group_size;
+    const int group = l * groups_per_traj + s / group_size;
+    uint32_t *pass = g.pass, *hit = g.hit;       // single shared map (the launcher guarantees it)
+    if (threadIdx.x == 0) {
+        src.scan_const(l, s, g, sc);
+        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN;
+    }
+    __syncthreads();
+    unsigned nvis = 0;
+    int bad = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const size_t rid = ((size_t)l * scans + s) * n + i;
+        RayRec rec;
+        rec.flags = 0; rec.x0 = rec.y0 = rec.dx = rec.yend = 0; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+        int pox, poy, b2 = 0;
+        Ray ry;
+        if (src.ray(l, s, i, sc, g, pox, poy, b2) && ray_setup(sc.pcx, sc.pcy, pox, poy, ry)) {
+            const bool record = ry.dx < kTileSteps;
+            const int klast = ry.flag ? 0 : ry.dx;
+            uint32_t *bw = ts.bits + rid * kTileWords;
+            unsigned short *pw = ts.prefix + rid * kTileWords;
+            double error = 0.0;
+            int y = ry.y0, hx = -1, hy = -1;
+            uint32_t word = 0, count = 0;
+            for (int k = 0; k <= ry.dx; ++k) {
+                if (record && (k & 31) == 0) pw[k >> 5] = (unsigned short)count;
+                int x = ry.x0 + k;
+                int lx = ry.steep ? y : x, ly = ry.steep ? x : y;
+                bool inmap = (unsigned)lx < (unsigned)g.xw && (unsigned)ly < (unsigned)g.yw;
+                nvis += inmap ? 1u : 0u;
+                if (k == klast) { hx = lx; hy = ly; }
+                else if (!record && inmap) atomicAdd(&pass[(size_t)lx * g.yw + ly], 1u);
+                if (k == ry.dx) rec.yend = y;
+                error += ry.derr;
+                bool stepy = error >= 0.5;
+                if (stepy) { y += ry.ystep; error -= 1.0; word |= 1u << (k & 31); ++count; }
+                if (record && ((k & 31) == 31 || k == ry.dx)) { bw[k >> 5] = word; word = 0; }
+            }
+            if ((unsigned)hx < (unsigned)g.xw && (unsigned)hy < (unsigned)g.yw) atomicAdd(&hit[(size_t)hx * g.yw + hy], 1u);
+            if (record) {
+                rec.x0 = ry.x0; rec.y0 = ry.y0; rec.dx = ry.dx;
+                rec.flags = 8u | (ry.steep ? 1u : 0u) | (ry.flag ? 2u : 0u) | (ry.ystep > 0 ? 4u : 0u);
+                int a0 = ry.x0, a1 = ry.x0 + ry.dx, b0 = min(ry.y0, rec.yend), b1 = max(ry.y0, rec.yend);
+                int mx0 = ry.steep ? b0 : a0, mx1 = ry.steep ? b1 : a1, my0 = ry.steep ? a0 : b0, my1 = ry.steep ? a1 : b1;
+                atomicMin(&box[0], mx0); atomicMin(&box[1], my0); atomicMax(&box[2], mx1); atomicMax(&box[3], my1);
+            }
+        }
+        bad |= b2;
+        ts.recs[rid] = rec;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && box[0] <= box[2]) {
+        atomicMin(&ts.gbox[4 * group], box[0]); atomicMin(&ts.gbox[4 * group + 1], box[1]);
+        atomicMax(&ts.gbox[4 * group + 2], box[2]); atomicMax(&ts.gbox[4 * group + 3], box[3]);
+    }
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if ((threadIdx.x & 63) == 0) {
+        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
+        if (anybad) atomicOr(g.status, anybad);
+    }
+}
+
+// Pass B: workgroup (tile, group): the pass counts of one map tile from one group of scans.
+__global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, int tiles_x, int rays_per_group, long total_rays)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned *win = reinterpret_cast<unsigned *>(smem);
+    __shared__ int next_ray;
+    const int tile = blockIdx.x, group = blockIdx.y;
+    const int tx0 = (tile % tiles_x) * kTileSide, ty0 = (tile / tiles_x) * kTileSide;
+    const int W = min(kTileSide, g.xw - tx0), H = min(kTileSide, g.yw - ty0);
+    const int tx1 = tx0 + W - 1, ty1 = ty0 + H - 1;
+    const int *gb = ts.gbox + 4 * group;
+    if (gb[0] > tx1 || gb[2] < tx0 || gb[1] > ty1 || gb[3] < ty0) return;   // nothing of this group comes near the tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int Hp2 = (H + 1) >> 1;
+    for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
+    if (tid == 0) next_ray = 0;
+    __syncthreads();
+    const long rbase = (long)group * rays_per_group;
+    const int nrays = (int)min((long)rays_per_group, total_rays - rbase);
+    uint32_t *pass = g.pass;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&next_ray, kWave);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= nrays) break;
+        if (base + lane >= nrays) continue;
+        const size_t rid = (size_t)(rbase + base + lane);
+        const RayRec rec = ts.recs[rid];
+        if (!(rec.flags & 8u)) continue;
+        const bool steep = rec.flags & 1u;
+        const int ystep = (rec.flags & 4u) ? 1 : -1;
+        const int klast = (rec.flags & 2u) ? 0 : rec.dx;
+        // tile range along the walk axis (a) and the other axis (b), in walk coordinates
+        const int a0 = steep ? ty0 : tx0, a1 = steep ? ty1 : tx1, b0 = steep ? tx0 : ty0, b1 = steep ? tx1 : ty1;
+        const int k0 = max(0, a0 - rec.x0), k1 = min(rec.dx, a1 - rec.x0);
+        if (k0 > k1 || min(rec.y0, rec.yend) > b1 || max(rec.y0, rec.yend) < b0) continue;
+        const uint32_t *bw = ts.bits + rid * kTileWords;
+        int w = k0 >> 5;
+        uint32_t word = bw[w];
+        int y = rec.y0 + ystep * ((int)ts.prefix[rid * kTileWords + w] + __popc(word & ((1u << (k0 & 31)) - 1u)));
+        word >>= (k0 & 31);
+        // cell of walk step k in window coordinates, advanced incrementally
+        int wa = rec.x0 + k0 - a0;                                   // along the walk axis: 0 .. a1 - a0
+        bool gone = false;
+        for (int k = k0; k <= k1 && !gone;) {
+            const int kend = min(k1, (w << 5) + 31);
+            const uint32_t next = kend < k1 ? bw[w + 1] : 0u;        // in flight while this word is walked
+            for (; k <= kend; ++k, ++wa) {
+                if (ystep > 0 ? y > b1 : y < b0) { gone = true; break; }   // left the tile for good (y is monotone)
+                if (y >= b0 && y <= b1 && k != klast) {
+                    unsigned wb = (unsigned)(y - b0);
+                    unsigned wx = steep ? wb : (unsigned)wa, wy = steep ? (unsigned)wa : wb;
+                    atomicAdd(&win[wx * Hp2 + (wy >> 1)], 1u << ((wy & 1u) * 16u));
+                }
+                y += (word & 1u) ? ystep : 0;
+                word >>= 1;
+            }
+            word = next;
+            ++w;
+        }
+    }
+    __syncthreads();
+    const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)W);
+    for (int rr = wave; rr < W; rr += nwaves) {
+        const int row = rr + rot < W ? rr + rot : rr + rot - W;
+        size_t gbase = (size_t)(tx0 + row) * g.yw + ty0;
+        for (int d = lane; d < Hp2; d += kWave) {
+            unsigned v = win[row * Hp2 + d];
+            unsigned p0 = v & 0xffffu, p1 = v >> 16;
+            if (p0) atomicAdd(&pass[gbase + 2 * d], p0);
+            if (p1) atomicAdd(&pass[gbase + 2 * d + 1], p1);
+        }
+    }
+}
+
+size_t tile_scratch_bytes(long rays, long groups)
+{
+    // (groups: an upper bound is enough - one per scan)
+    return (size_t)rays * (sizeof(RayRec) + kTileWords * 4 + kTileWords * 2) + (size_t)groups * 16 + 1024;
+}
+
+bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj)
+{
+    // one shared map, much larger than a window; a group's ray count must fit the 16-bit tile counters
+    return !got && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= 8192;
+}
+
+hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                    const double *poses, const double *centres, int L, int n_scan, int n, int group,
+                                    void *scratch, hipStream_t s)
+{
+    if (n_scan < 2) return hipSuccess;
+    const int scans = n_scan - 1;
+    int G = group > 0 ? group : 8;
+    G = std::min(G, std::max(1, 65535 / n));
+    G = std::min(G, scans);
+    if (L > 1)                                    // a group is a contiguous range of ray ids: it must not straddle streams
+        while (scans % G != 0) --G;
+    const int groups_per_traj = (scans + G - 1) / G;
+    const long groups = (long)L * groups_per_traj, rays = (long)L * scans * n;
+    if (groups > 65535) return hipErrorInvalidValue;
+    TileScratch ts;
+    char *p = static_cast<char *>(scratch);
+    ts.recs = reinterpret_cast<RayRec *>(p); p += (size_t)rays * sizeof(RayRec);
+    ts.bits = reinterpret_cast<uint32_t *>(p); p += (size_t)rays * kTileWords * 4;
+    ts.prefix = reinterpret_cast<unsigned short *>(p); p += (size_t)rays * kTileWords * 2;
+    ts.gbox = reinterpret_cast<int *>(p);
+    if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
+    // the family is three launches: bracket it with recorded events when timing is armed
+    LaunchEvents ev = g_launch_ev;
+    g_launch_ev = {nullptr, nullptr};
+    if (ev.e0) (void)hipEventRecord(ev.e0, s);
+    hipLaunchKernelGGL(k_tile_init, dim3((groups + 255) / 256), dim3(256), 0, s, ts.gbox, (int)groups);
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
+    hipLaunchKernelGGL((k_ray_bits<ReplaySource>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
+    const int tiles_x = (g.xw + kTileSide - 1) / kTileSide, tiles_y = (g.yw + kTileSide - 1) / kTileSide;
+    size_t lds = (size_t)kTileSide * (kTileSide / 2) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_cast),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_tile_cast, dim3(tiles_x * tiles_y, (unsigned)groups), dim3(512), lds, s, g, ts, tiles_x, G * n, rays);
+    if (ev.e1) (void)hipEventRecord(ev.e1, s);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,
                                                        size_t cells, OccRule rule, int8_t *__restrict__ pmap)
 {

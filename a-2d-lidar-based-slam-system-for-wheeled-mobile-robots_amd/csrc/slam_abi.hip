@@ -70,6 +70,7 @@ struct slam_ctx {
     bool own_stream = false;
     Arena staging;   // device copies of host arguments (host-pointer entry points)
     Arena scratch;   // temporaries of *_dev sequences
+    Arena tiles;     // recorded walks of the tiled ray cast
     int *status = nullptr;
     bool timing = false;
     std::vector<hipEvent_t> pool;
@@ -300,6 +301,7 @@ int slam_destroy(slam_ctx *c)
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->staging.base) (void)hipFree(c->staging.base);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
+    if (c->tiles.base) (void)hipFree(c->tiles.base);
     if (c->status) (void)hipFree(c->status);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -324,7 +326,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
 {
     TRY(use(c));
     REQUIRE(name, "null name");
-    if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1, "grid_mode is 0 or 1"); c->grid_mode = (int)value; }
+    if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "grid_mode is 0..3"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
     else if (!strcmp(name, "pipeline")) {
         REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
@@ -687,6 +689,34 @@ int slam_grid_update(slam_ctx *c, slam_grid *g, const double *ox, const double *
     return check_status_sync(c);
 }
 
+// Ray cast of L streams x (n_scan - 1) scans into `g` on stream st, choosing the kernel:
+// grid_mode 0 direct atomics, 1 automatic (LDS window; recorded walks + tiles for maps much
+// larger than a window), 2 always tiles (where they apply), 3 always the window.
+static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const double *cos_t, const double *sin_t,
+                       const double *poses, const double *centres, int L, int n_scan, int n, const int32_t *got,
+                       hipStream_t st)
+{
+    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || (c->grid_mode == 2 && !got);
+    if ((c->grid_mode == 1 || c->grid_mode == 2) && tiles_ok) {
+        long rays = (long)L * (n_scan - 1) * n, groups = (long)L * (n_scan - 1);
+        size_t need = tile_scratch_bytes(rays, groups);
+        if (need > c->tiles.cap) {
+            if (c->gstream) HIPCHK(hipStreamSynchronize(c->gstream));
+            TRY(arena_reserve(c, c->tiles, need));
+        }
+        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st));
+        return SLAM_OK;
+    }
+    if (c->grid_mode != 0) {
+        if (centres) HIPCHK(launch_grid_update_scans(g->d, ranges + n, cos_t, sin_t, poses, centres, n_scan - 1, n, c->grid_group, st));
+        else HIPCHK(launch_grid_update_replay_win(g->d, ranges, cos_t, sin_t, poses, L, n_scan, n, got, c->grid_group, st));
+        return SLAM_OK;
+    }
+    REQUIRE(!centres, "grid_mode 0 has no separate ray origins");
+    HIPCHK(launch_grid_update_replay(g->d, ranges, cos_t, sin_t, poses, L, n_scan, n, got, st));
+    return SLAM_OK;
+}
+
 int slam_grid_update_scans_dev(slam_ctx *c, slam_grid *g, const float *ranges, const double *cos_t, const double *sin_t,
                                const double *poses, const double *centres, int S, int n)
 {
@@ -695,8 +725,8 @@ int slam_grid_update_scans_dev(slam_ctx *c, slam_grid *g, const float *ranges, c
     REQUIRE(g && ranges && cos_t && sin_t && poses, "null pointer");
     REQUIRE(S > 0 && n > 0 && n <= 65535, "bad sizes");
     Timed t(c, SLAM_K_GRID);
-    HIPCHK(launch_grid_update_scans(g->d, ranges, cos_t, sin_t, poses, centres, S, n, c->grid_group, c->stream));
-    return SLAM_OK;
+    // scan k of cast_replay's stream is ranges[k + 1]: shift the base by one scan
+    return cast_replay(c, g, ranges - n, cos_t, sin_t, poses, centres, 1, S + 1, n, nullptr, c->stream);
 }
 
 int slam_grid_update_scans(slam_ctx *c, slam_grid *g, const float *ranges, const double *cos_t, const double *sin_t,
@@ -922,11 +952,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         if (grid) {
             TRY(grid_on_main(c));
             Timed t(c, SLAM_K_GRID);
-            if (c->grid_mode == 1)
-                HIPCHK(launch_grid_update_replay_win(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj,
-                                                     c->grid_group, c->stream));
-            else
-                HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->stream));
+            TRY(cast_replay(c, grid, ranges, cos_t, sin_t, poses_out, nullptr, L, n_scan, n, grid_of_traj, c->stream));
         }
         return SLAM_OK;
     }
@@ -943,11 +969,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
     c->mgrid = false;
     {
         Timed t(c, SLAM_K_GRID, c->gstream);
-        if (c->grid_mode == 1)
-            HIPCHK(launch_grid_update_replay_win(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj,
-                                                 c->grid_group, c->gstream));
-        else
-            HIPCHK(launch_grid_update_replay(grid->d, ranges, cos_t, sin_t, poses_out, L, n_scan, n, grid_of_traj, c->gstream));
+        TRY(cast_replay(c, grid, ranges, cos_t, sin_t, poses_out, nullptr, L, n_scan, n, grid_of_traj, c->gstream));
     }
     HIPCHK(hipEventRecord(c->ev_cast[c->cast_pos], c->gstream));
     c->cast_poses[c->cast_pos] = poses_out;

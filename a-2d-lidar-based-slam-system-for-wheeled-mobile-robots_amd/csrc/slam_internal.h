@@ -105,6 +105,12 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
                                          int grid_per_traj = 0);
 hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int S, int n, int group, hipStream_t s);
+// Tiled path for maps much larger than an LDS window (single shared map, ReplaySource only).
+size_t tile_scratch_bytes(long rays, long groups);
+bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj);
+hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                    const double *poses, const double *centres, int L, int n_scan, int n, int group,
+                                    void *scratch, hipStream_t s);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
 hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);

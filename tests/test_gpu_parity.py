@@ -526,7 +526,7 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     ctx = slam.Context(0)
     og = co.Grid(2000, 2000, 50.0, 20.0, 20.0)
     oposes, _, _, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8, mt_grid=True)
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):        # direct atomics, automatic (= tiles on a map this large), tiles, window
         ctx.set_option("grid_mode", mode)
         ctx.set_option("grid_group", group)
         grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02, context=ctx)
@@ -545,6 +545,53 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     r = grid.read(0, want=("pass", "hit"))
     assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
     grid.close()
+    ctx.close()
+
+
+def test_tiled_ray_cast_cases(slam, syn):
+    """The recorded-walk + tile path (grid_mode 2) beyond the common case: several streams into
+    one map, a small map (tiles forced), rays longer than the 2048 recorded steps (walked
+    directly), rays leaving the map, and separate ray origins."""
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", 2)
+    # (a) three streams of 12 scans into one 400x400 map
+    reps = [syn.make_replay(13, 200, seed=s, stride=5) for s in (7, 8, 9)]
+    ranges = np.stack([r.ranges for r in reps])
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    ov = 0
+    for r in ranges:
+        _, _, _, v = co.replay(r, AMIN, AMAX, og, threads=8, mt_grid=True)
+        ov += v
+    for group in (0, 5):                                     # 5 does not divide 12: the group size is lowered
+        ctx.set_option("grid_group", group)
+        grid = slam.DeviceGrid.metric(1, 400, 400, 0.05, context=ctx)
+        slam.replay_host(ranges, AMIN, AMAX, grid=grid, grid_of_traj=None, context=ctx)
+        r = grid.read(0, want=("pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and grid.visits() == ov
+        grid.close()
+    ctx.set_option("grid_group", 0)
+    # (b) 0.004 m cells: most rays are longer than 2048 steps; the map (3000^2) holds only part of the room
+    rep = syn.make_replay(9, 120, seed=11, stride=5)
+    og = co.Grid(3000, 3000, 250.0, 6.0, 6.0)
+    oposes, _, _, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8, mt_grid=True)
+    grid = slam.DeviceGrid(1, 3000, 3000, 250.0, 6.0, 6.0, context=ctx)
+    slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, context=ctx)
+    r = grid.read(0, want=("pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and grid.visits() == ov
+    assert int(r["pass"].max()) > 0
+    grid.close()
+    # (c) separate ray origins (slam_grid_update_scans) through the tiled path
+    rep = syn.make_replay(12, 200, seed=12, stride=5)
+    poses = np.ascontiguousarray(rep.poses_true[:12])
+    centres = poses[:, :2] + np.random.default_rng(4).normal(0, 0.05, size=(12, 2))
+    m = slam.Mapping(200, 200, 0.1, context=ctx)
+    m.update_scans(rep.ranges[:12], AMIN, AMAX, poses, centres)
+    o = on.Mapping(200, 200, 0.1)
+    for k in range(12):
+        obs = on.world_points(poses[k], on.laser_to_numpy(rep.ranges[k], AMIN, AMAX, clip_inf=True))
+        o.update(obs[0], obs[1], centres[k][0], centres[k][1])
+    p, h = m.counters()
+    assert np.array_equal(p, o.pass_cnt) and np.array_equal(h, o.hit_cnt)
     ctx.close()
 
 
