@@ -71,9 +71,11 @@ def particles(slam, torch, P, steps, warmup, live=True):
             "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
 
 
-def replay(slam, torch, scans, beams, grid_n, reso, room, points, steps, warmup, label):
+def replay(slam, torch, scans, beams, grid_n, reso, room, points, steps, warmup, label, grid_group=0, grid_mode=1):
     rep = slam.synthetic.make_replay(scans, beams, seed=3 if beams == 1080 else 1, room_scale=room, stride=5)
     dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype=points)
+    dr.ctx.set_option("grid_group", grid_group)
+    dr.ctx.set_option("grid_mode", grid_mode)
     grid = dr.make_grid(1, grid_n, grid_n, reso)
     pmap = torch.empty((grid_n, grid_n), dtype=torch.int8, device=dr.dev)
     A = slam._abi
@@ -140,6 +142,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="particles,dense,long")
     ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--grid-group", type=int, default=0)
+    ap.add_argument("--grid-mode", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
@@ -154,7 +158,8 @@ def main():
             out = mapobs(slam, torch, 4096, args.steps, args.warmup)
         elif w == "dense":
             out = replay(slam, torch, 1000, 1080, 2000, 0.02, 2.0, "f16", args.steps, args.warmup,
-                         "configs[4]: 1k-scan replay, 1080 beams, 2000x2000@0.02m grid, f16 point buffers, room x2")
+                         "configs[4]: 1k-scan replay, 1080 beams, 2000x2000@0.02m grid, f16 point buffers, room x2",
+                         grid_group=args.grid_group, grid_mode=args.grid_mode)
         elif w == "long":
             out = replay(slam, torch, 5000, 360, 400, 0.05, 1.0, "f64", args.steps, args.warmup,
                          "configs[3] per-GPU share: 5k-scan replay, 360 beams, 400x400@0.05m grid")
