@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--points", default="f64", choices=["f64", "f32", "f16"],
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
-    ap.add_argument("--grid-mode", type=int, default=1, help="1: LDS-window ray casting (default), 0: direct global atomics")
+    ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window here; tiles on maps much larger than a window), 0: direct global atomics, 2: tiles, 3: window")
     ap.add_argument("--grid-group", type=int, default=0, help="scans per workgroup in window mode (0: automatic)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
     ap.add_argument("--time-lane0-only", action="store_true", help="HIP events on lane 0 only (default: every lane)")
@@ -243,7 +243,7 @@ def main():
                  "finalize": args.grid * args.grid * 9}.get(dom, 0)
     kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "compose": "k_pose_compose",
              "finalize": "k_grid_finalize"}.get(dom, dom)
-    if dom == "grid" and args.grid_mode == 1:
+    if dom == "grid" and args.grid_mode in (1, 3):
         kname = "k_grid_update_win"
     traffic, tsrc, valu_busy = load_traffic(kname)
     achieved = alg_bytes / avg_s / 1e9

@@ -72,15 +72,18 @@ int slam_synchronize(slam_ctx *ctx);
 /* Synchronise and return-and-clear the sticky data error raised by kernels since the
  * last call (SLAM_OK, SLAM_ERR_NAN or SLAM_ERR_OVERFLOW). */
 int slam_check_status(slam_ctx *ctx);
-/* Tuning knobs (results never depend on them).  "grid_mode": 1 = ray casting through an
- * LDS window per group of scans (default), 0 = direct global atomics.  "grid_group": scans
- * per workgroup in window mode, 0 = automatic.  "pipeline": 1 = slam_replay_dev with a
- * map runs as three stages on three streams of the context (scan matching | pose composition |
- * slam_grid_reset -> ray cast -> slam_grid_finalize_dev), so the map stage of one replay
- * overlaps the scan matching of the next; give consecutive replays different poses_out and
- * T_out buffers to benefit (a buffer an earlier stage is still reading is waited for).  Results of the later stages (poses_out, pmap_dev) are visible
- * after slam_synchronize / a device synchronise, or to any later call on this context;
- * 0 = everything on the context's stream (default). */
+/* Tuning knobs (results never depend on them).
+ * "grid_mode": 1 = automatic (default): ray casting through an LDS window per group of scans,
+ *   or - for one shared map much larger than a window - walks recorded once and cast tile by
+ *   tile; 0 = direct global atomics; 2 = tiles wherever they apply; 3 = always the window.
+ * "grid_group": scans per workgroup / per tile group, 0 = automatic.
+ * "pipeline": 1 = slam_replay_dev with a map runs as three stages on three streams of the
+ *   context (scan matching | pose composition | slam_grid_reset -> ray cast ->
+ *   slam_grid_finalize_dev), so the map stage of one replay overlaps the scan matching of the
+ *   next; give consecutive replays different poses_out and T_out buffers to benefit (a buffer an
+ *   earlier stage is still reading is waited for).  Results of the later stages (poses_out,
+ *   pmap_dev) are visible after slam_synchronize / a device synchronise, or to any later call
+ *   on this context.  0 = everything on the context's stream (default). */
 int slam_set_option(slam_ctx *ctx, const char *name, double value);
 /* Per-kernel-family timing with HIP events on the context's stream (bench.py roofline).
  * read: synchronises, adds up elapsed ms and launch counts since the last reset. */
