@@ -820,6 +820,12 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
         for (int k = k0; k <= k1 && !gone;) {
             const int kend = min(k1, (w << 5) + 31);
             const uint32_t next = kend < k1 ? bw[w + 1] : 0u;        // in flight while this word is walked
+            const int nb = kend - k + 1;
+            const int yafter = y + ystep * __popc(nb == 32 ? word : (word & ((1u << nb) - 1u)));
+            if (ystep > 0 ? yafter < b0 : yafter > b1) {             // the whole word stays short of the tile's rows
+                y = yafter; k = kend + 1; wa += nb; word = next; ++w;
+                continue;
+            }
             for (; k <= kend; ++k, ++wa) {
                 if (ystep > 0 ? y > b1 : y < b0) { gone = true; break; }   // left the tile for good (y is monotone)
                 if (y >= b0 && y <= b1 && k != klast) {
