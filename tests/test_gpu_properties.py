@@ -122,3 +122,50 @@ def test_bresenham_random_lines(slam, seed, B, span):
     e = s + rng.integers(-span, span + 1, size=(B, 2))
     for p, a, b in zip(slam.rasterize(s, e), s, e):
         assert np.array_equal(p, co.bresenham(a, b))
+
+
+@settings(**{**SET, "max_examples": 40})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 300), S=st.integers(1, 9), mode=st.sampled_from([0, 1, 2, 3]),
+       group=st.sampled_from([0, 1, 3, 64]), xw=st.sampled_from([40, 200, 500]), scale=st.sampled_from([5.0, 20.0, 100.0]),
+       hit_inc=st.sampled_from([20.0, 4.0]), live=st.booleans(), centres=st.booleans())
+def test_scan_casting_all_paths_agree(slam, seed, n, S, mode, group, xw, scale, hit_inc, live, centres):
+    """slam_grid_update_scans through every ray-cast path (direct atomics, window, recorded walks +
+    tiles), any group size, both evidence rules, with and without the live pmap and separate ray
+    origins: counters, pmap and the visit count equal the oracle's."""
+    from oracle import oracle_np as on
+    rng = np.random.default_rng(seed)
+    yw = xw if seed % 2 else xw + 12
+    off_x, off_y = xw / (2 * scale), yw / (2 * scale)
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", mode)
+    ctx.set_option("grid_group", group)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, hit_inc=hit_inc, context=ctx)
+    if live:
+        g.live_pmap()
+    poses = np.stack([rng.uniform(-off_x, off_x, S), rng.uniform(-off_y, off_y, S), rng.uniform(-4, 4, S)], axis=1)
+    ctr = poses[:, :2] + rng.normal(0, 0.3, (S, 2)) if centres and mode != 0 else None
+    ranges = rng.uniform(0.05, 2.5 * off_x, (S, n)).astype(np.float32)
+    if seed % 5 == 0:
+        ranges[0, : max(1, n // 4)] = np.inf                    # clipped to 30 m: mostly leaves the map
+    amin, amax = -3.14159, 3.14159
+    ct, st_ = slam._abi.trig_tables(amin, amax, n)
+    A = slam._abi
+    A.check(A.lib().slam_grid_update_scans(ctx.handle, g._h, A.ptr(ranges), A.ptr(ct), A.ptr(st_), A.ptr(poses),
+                                           A.ptr(None if ctr is None else np.ascontiguousarray(ctr)), S, n))
+    og = co.Grid(xw, yw, scale, off_x, off_y, hit_inc=hit_inc)
+    for k in range(S):
+        pc = on.laser_to_numpy(ranges[k], amin, amax, clip_inf=True)
+        obs = on.world_points(poses[k], pc)
+        c = poses[k, :2] if ctr is None else ctr[k]
+        og.update(obs[0], obs[1], c[0], c[1])
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+    assert g.visits() == og.visits
+    table = on.occupied_rule(0.01, hit_inc, 10.0)
+    p, h = og.pass_cnt.astype(np.int64), og.hit_cnt.astype(np.int64)
+    occ = h >= len(table)
+    for lvl, t in enumerate(table):
+        occ |= (h == lvl) & (p >= t)
+    assert np.array_equal(r["pmap"], np.where((p + h) > 0, np.where(occ, 100, 0), 50).astype(np.int8))
+    g.close()
+    ctx.close()
