@@ -237,7 +237,10 @@ constexpr int kWinCells = 36864;     // 16-bit cells: 72 KiB of LDS
 constexpr int kWinMaxGroup = 64;     // scans per workgroup
 constexpr int kSortBins = 128;        // ray-length histogram (4 cells per bin)
 constexpr int kMaxSortRays = 8192;    // rays per workgroup that can be length-sorted (u16 ids in LDS)
-constexpr int kRaysPerLane = 4;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
+#ifndef SLAM_RAYS_PER_LANE
+#define SLAM_RAYS_PER_LANE 4
+#endif
+constexpr int kRaysPerLane = SLAM_RAYS_PER_LANE;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
 
 // mapping.py:47-50 applied to the integer counters (see the header comment).
 struct OccRule {
