@@ -15,7 +15,7 @@ plus the batched forms used by bench.py (``replay``) and the multi-GPU sharding 
 (``dist``).  Importing the package never computes anything; every operator raises if
 libslamhip.so or the GPU is missing (there is no CPU implementation in the product).
 """
-from . import _abi, param, synthetic
+from . import _abi, dist, param, synthetic
 from ._abi import Context, LibraryMissing, SlamError, default_context
 from .bresenham import bresenham, rasterize
 from .ekf_lm import EKF

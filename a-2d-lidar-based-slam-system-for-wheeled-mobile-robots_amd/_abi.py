@@ -73,6 +73,7 @@ _SIGS = {
     "slam_replay": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "slam_particles": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp], _i),
     "slam_particles_dev": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp], _i),
+    "slam_grid_counters_dev": ([_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)], _i),
     "slam_grid_live_pmap": ([_vp, _vp, C.POINTER(_vp)], _i),
     "slam_grid_update_scans": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),
     "slam_grid_update_scans_dev": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i], _i),

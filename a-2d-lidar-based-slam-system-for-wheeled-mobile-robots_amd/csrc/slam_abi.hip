@@ -823,6 +823,17 @@ int slam_grid_read(slam_ctx *c, slam_grid *g, int gi, int8_t *pmap, double *data
     return SLAM_OK;
 }
 
+int slam_grid_counters_dev(slam_ctx *c, slam_grid *g, uint32_t **pass_dev, uint32_t **hit_dev)
+{
+    TRY(use(c));
+    REQUIRE(g && pass_dev && hit_dev, "null pointer");
+    TRY(grid_on_main(c));                 // later work on the context's stream sees every update so far
+    if (g->pmap_live) g->live_dirty = true;   // the caller may change the counters behind the library's back
+    *pass_dev = g->d.pass;
+    *hit_dev = g->d.hit;
+    return SLAM_OK;
+}
+
 int slam_grid_occupancy_data(slam_ctx *c, slam_grid *g, int gi, int8_t *data)
 {
     TRY(use(c));

@@ -86,6 +86,17 @@ def all_reduce_counters(pass_cnt, hit_cnt, device=None):
     return outs[0], outs[1]
 
 
+def all_reduce_grid(grid):
+    """Merge the maps that the ranks built from disjoint scans: one in-place RCCL
+    ``all_reduce(SUM)`` per counter array, on the device (``grid``: a :class:`DeviceGrid`)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    p, h = grid.counters_torch()
+    dist.all_reduce(p, op=dist.ReduceOp.SUM)
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+
+
 def hip_runner(ranges, angle_min, angle_max, max_iter, tolerance, local_rank):
     """Default compute: this rank's trajectories on its GPU (DeviceReplay, no map)."""
     from .replay import DeviceReplay

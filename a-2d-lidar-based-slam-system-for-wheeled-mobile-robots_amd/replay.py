@@ -130,6 +130,21 @@ class DeviceGrid:
     def reset(self):
         _abi.check(_abi.lib().slam_grid_reset(self._ctx.handle, self._h))
 
+    def counters_torch(self):
+        """(pass, hit) as torch int32 tensors [G, xw, yw] that ALIAS the device counters (the
+        uint32 bits viewed as int32: sums wrap identically) - for checkpoint / restore
+        (``.clone()`` / ``.copy_()``) and for ``torch.distributed.all_reduce`` across ranks."""
+        import torch
+        p, h = C.c_void_p(), C.c_void_p()
+        _abi.check(_abi.lib().slam_grid_counters_dev(self._ctx.handle, self._h, C.byref(p), C.byref(h)))
+
+        class _View:                      # minimal __cuda_array_interface__ carrier
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+        shape = (self.G, self.xw, self.yw)
+        dev = torch.device("cuda", self._ctx.device)
+        return (torch.as_tensor(_View(p.value, shape), device=dev), torch.as_tensor(_View(h.value, shape), device=dev))
+
     def live_pmap(self):
         """Keep ``pmap`` [G, xw, yw] int8 resident and current on the device
         (``slam_grid_live_pmap``); returns its device address."""

@@ -173,6 +173,13 @@ int slam_grid_update_scans_dev(slam_ctx *ctx, slam_grid *grid, const float *rang
  * = free_inc*pass + hit_inc*hit; pass, hit [xw][yw] uint32. */
 int slam_grid_read(slam_ctx *ctx, slam_grid *grid, int g, int8_t *pmap, double *datamap, uint32_t *pass,
                    uint32_t *hit);
+/* Device addresses of the evidence counters, pass and hit, each uint32 [G][xw][yw]: for
+ * checkpoint / restore and for merging maps that several GPUs built from disjoint scans - one
+ * all_reduce(SUM) over the ranks, in place (integer sums commute, so the merged map is
+ * bit-identical for any rank count).  Work enqueued on the context's stream after
+ * this call sees every earlier update; a live pmap is marked stale. */
+int slam_grid_counters_dev(slam_ctx *ctx, slam_grid *grid, uint32_t **pass_dev, uint32_t **hit_dev);
+
 /* Keep pmap [G][xw][yw] int8 resident and current on the device and return its address.
  * Ray casts that are the only writer of their map in a launch (one scan group per map: the
  * per-particle maps of slam_particles, Mapping.update of one scan) re-threshold just the cells

@@ -471,6 +471,45 @@ def test_live_pmap_matches_finalize(slam, syn):
     assert np.all(outs[1][2] == 50) and not np.array_equal(outs[1][0], outs[1][1])
 
 
+def test_counters_alias_checkpoint_and_merge(slam, syn):
+    """slam_grid_counters_dev: the torch views alias the device counters - checkpoint / restore,
+    and the merge of maps built from disjoint scans (what all_reduce(SUM) does across ranks) is
+    the map built from all of them."""
+    import torch
+    rep = syn.make_replay(41, 360, seed=5, stride=5)
+    whole = slam.DeviceGrid.metric(1, 400, 400, 0.05)
+    poses, _, _ = slam.replay_host(rep.ranges, AMIN, AMAX, grid=whole)
+    want = whole.read(0, want=("pmap", "pass", "hit"))
+    # two "ranks": scans 1..20 and 21..40 cast from the same poses into two maps, then summed in place
+    parts = []
+    for lo, hi in ((0, 20), (20, 40)):
+        g = slam.DeviceGrid.metric(1, 400, 400, 0.05)
+        g.live_pmap()
+        m_ranges = np.ascontiguousarray(rep.ranges[1 + lo:1 + hi])
+        ct, st = slam._abi.trig_tables(AMIN, AMAX, 360)
+        A = slam._abi
+        A.check(A.lib().slam_grid_update_scans(g._ctx.handle, g._h, A.ptr(m_ranges), A.ptr(ct), A.ptr(st),
+                                               A.ptr(np.ascontiguousarray(poses[lo:hi])), None, hi - lo, 360))
+        parts.append(g)
+    p0, h0 = parts[0].counters_torch()
+    p1, h1 = parts[1].counters_torch()
+    assert p0.dtype == torch.int32 and tuple(p0.shape) == (1, 400, 400) and p0.is_cuda
+    snap = (p0.clone(), h0.clone())                           # checkpoint of part 0
+    p0 += p1
+    h0 += h1
+    torch.cuda.synchronize()
+    got = parts[0].read(0, want=("pmap", "pass", "hit"))      # the live pmap was marked stale -> refreshed
+    assert np.array_equal(got["pass"], want["pass"]) and np.array_equal(got["hit"], want["hit"])
+    assert np.array_equal(got["pmap"], want["pmap"])
+    p0.copy_(snap[0]); h0.copy_(snap[1])                      # restore
+    torch.cuda.synchronize()
+    p0b, _ = parts[0].counters_torch()
+    back = parts[0].read(0, want=("pass", "hit", "pmap"))
+    assert int(back["pass"].astype(np.int64).sum() + back["hit"].astype(np.int64).sum()) < int(want["pass"].astype(np.int64).sum())
+    assert np.array_equal(back["pass"], snap[0].cpu().numpy()[0].astype(np.uint32)) and p0b.data_ptr() == p0.data_ptr()
+    slam.dist.all_reduce_grid(parts[0])                       # no process group: a no-op
+
+
 def test_pipelined_map_stage_is_bit_identical(slam, syn):
     """"pipeline" option: the map stage on a second stream (overlapping the next replay's scan
     matching) gives the same bits as the serial order, with alternating AND with reused pose
