@@ -10,7 +10,10 @@ from oracle import c_oracle as co
 
 pytestmark = pytest.mark.gpu
 FTOL = 1e-9
-SET = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+import os
+
+# SLAM_HYP_EXAMPLES=1000 turns the suite into a soak run
+SET = dict(max_examples=int(os.environ.get("SLAM_HYP_EXAMPLES", "60")), deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 @pytest.fixture(scope="module")
@@ -124,7 +127,7 @@ def test_bresenham_random_lines(slam, seed, B, span):
         assert np.array_equal(p, co.bresenham(a, b))
 
 
-@settings(**{**SET, "max_examples": 40})
+@settings(**{**SET, "max_examples": max(40, SET["max_examples"] * 2 // 3)})
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 300), S=st.integers(1, 9), mode=st.sampled_from([0, 1, 2, 3]),
        group=st.sampled_from([0, 1, 3, 64]), xw=st.sampled_from([40, 200, 500]), scale=st.sampled_from([5.0, 20.0, 100.0]),
        hit_inc=st.sampled_from([20.0, 4.0]), live=st.booleans(), centres=st.booleans())
