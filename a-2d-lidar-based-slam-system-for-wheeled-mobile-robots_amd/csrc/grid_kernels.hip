@@ -233,7 +233,10 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
 // around the first origin; cells of a ray outside the window fall back to direct global
 // atomics, so the result is exact for any window.
 // ---------------------------------------------------------------------------------
-constexpr int kWinCells = 36864;     // 16-bit cells: 72 KiB of LDS
+#ifndef SLAM_WIN_CELLS
+#define SLAM_WIN_CELLS 36864
+#endif
+constexpr int kWinCells = SLAM_WIN_CELLS;     // 16-bit cells: 72 KiB of LDS
 constexpr int kWinMaxGroup = 64;     // scans per workgroup
 constexpr int kSortBins = 128;        // ray-length histogram (4 cells per bin)
 constexpr int kMaxSortRays = 8192;    // rays per workgroup that can be length-sorted (u16 ids in LDS)
@@ -402,16 +405,25 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
     return nvis;
 }
 
+__host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)group * sizeof(ScanConst) + 15) & ~(size_t)15; }
+__host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
+__host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap)
+{
+    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)kWinCells * 2;
+}
+
 template <class Src>
 __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got,
-                                                          int exclusive)
+                                                          int exclusive, int sort_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [kWinMaxGroup]
-    int *box = reinterpret_cast<int *>(smem + kWinMaxGroup * sizeof(ScanConst));          // bbox[4], window[4], flags
+    // LDS is carved for this launch's group size (win_lds_bytes): a small group leaves room for a
+    // second workgroup on the CU
+    ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [group_size]
+    int *box = reinterpret_cast<int *>(smem + win_sc_bytes(group_size));                  // bbox[4], window[4], flags
     int *hist = box + 16;                                                                 // [kSortBins]
-    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [kMaxSortRays]
-    unsigned *win = reinterpret_cast<unsigned *>(order + kMaxSortRays);                   // [W][Hp/2] dwords
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [sort_cap]
+    unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);                       // [W][Hp/2] dwords
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
@@ -426,7 +438,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const bool fused = exclusive && g.pmap_live && (g.yw & 3) == 0 && (((size_t)gi * g.xw * g.yw) & 3) == 0;
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
     if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; }
-    const bool sorted = nrays <= kMaxSortRays;
+    const bool sorted = nrays <= sort_cap;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
     if (tid < kSortBins) hist[tid] = 0;
     __syncthreads();
@@ -458,7 +470,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             if (fused) y0 &= ~3;                                      // quads of the fused flush line up with the window's dwords
             W = x1 - x0 + 1; H = y1 - y0 + 1;
             if ((long)W * ((H + 1) & ~1) > kWinCells) {               // keep a sub-rectangle around the first origin
-                int Hd = min(H, 192), Wd = min(W, kWinCells / Hd);
+                int Hd = min(H, 192), Wd = min(W, kWinCells / ((Hd + 1) & ~1));   // rows are stored padded to an even height
                 int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
                 if (fused) cy0 &= ~3;
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
@@ -584,12 +596,12 @@ template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
 {
-    size_t lds = kWinMaxGroup * sizeof(ScanConst) + 64 + kSortBins * 4 + kMaxSortRays * 2 + (size_t)kWinCells * 2;
+    const size_t lds_max = win_lds_bytes(kWinMaxGroup, kMaxSortRays);
     static bool attr_done[2] = {false, false};
     constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
     if (!attr_done[which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_win<Src>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) return e;
         attr_done[which] = true;
     }
@@ -606,7 +618,9 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     // operations in flight even when there are few rays (measured on 10 000 single-scan groups:
     // 2.88 ms with 128 threads, 2.05 ms with 512)
     if (threads < 512) threads = 512;
-    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), lds, s, g, src, group, got, exclusive);
+    const int sort_cap = win_sort_cap((long)group * n);
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap), s, g, src, group, got,
+                exclusive, sort_cap);
     return hipGetLastError();
 }
 
