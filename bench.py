@@ -287,8 +287,11 @@ def main():
         og = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
         op, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, max_iter=args.max_iter, tolerance=args.tol,
                                     threads=os.cpu_count() or 1, mt_grid=True)
+        cnt = grid.read(0, want=("pass", "hit"))
         out["parity"] = {"pose_max_abs_err": float(np.max(np.abs(poses[0] - op))), "iters_equal": bool(np.array_equal(iters[0], oit)),
-                         "pmap_cell_mismatches": int(np.sum(pmap.cpu().numpy() != og.pmap)), "visits_equal": bool(visits == ov)}
+                         "pmap_cell_mismatches": int(np.sum(pmap.cpu().numpy() != og.pmap)),
+                         "counter_cell_mismatches": int(np.sum(cnt["pass"] != og.pass_cnt) + np.sum(cnt["hit"] != og.hit_cnt)),
+                         "visits_equal": bool(visits == ov)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rep, args, args.cpu_seconds)
     if rank == 0:
