@@ -19,10 +19,13 @@ _bp = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    """Build (if stale) and return the path of the shared object; SLAM_ORACLE_LIB selects another
+    target of oracle/Makefile (liboracle_san.so: the AddressSanitizer / UBSan build)."""
+    name = os.environ.get("SLAM_ORACLE_LIB", "liboracle.so")
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "slam_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
     return so
 
 
