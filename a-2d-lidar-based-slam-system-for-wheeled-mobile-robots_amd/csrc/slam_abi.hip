@@ -124,10 +124,18 @@ int arena_reserve(slam_ctx *c, Arena &a, size_t bytes)
     return SLAM_OK;
 }
 
+// Next piece of a reserved arena.  A piece that does not fit (a reservation computed too small:
+// an internal error) comes back null, which the entry point's null checks / the first copy
+// into it turn into an error code instead of a silent overrun.
 template <typename T>
 T *carve(Arena &a, size_t count)
 {
     size_t off = align_up(a.used);
+    if (off + count * sizeof(T) > a.cap) {
+        a.used = a.cap + 1;
+        (void)fail(SLAM_ERR_NOMEM, "internal: workspace reservation too small (%zu > %zu bytes)", off + count * sizeof(T), a.cap);
+        return nullptr;
+    }
     a.used = off + count * sizeof(T);
     return reinterpret_cast<T *>(a.base + off);
 }
