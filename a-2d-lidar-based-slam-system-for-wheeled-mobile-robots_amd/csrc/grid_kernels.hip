@@ -409,7 +409,7 @@ __host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)grou
 __host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
 __host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap)
 {
-    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)kWinCells * 2;
+    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)kWinCells * 2 + kLdsGuard;
 }
 
 template <class Src>
@@ -424,6 +424,8 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     int *hist = box + 16;                                                                 // [kSortBins]
     unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [sort_cap]
     unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);                       // [W][Hp/2] dwords
+    char *guard = reinterpret_cast<char *>(win) + (size_t)kWinCells * 2;
+    lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
@@ -590,6 +592,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
         }
     }
+    lds_guard_check(guard, g.status);
 }
 
 template <class Src>
@@ -804,6 +807,8 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int Hp2 = (H + 1) >> 1;
     const int Hs = Hp2 | 1;                      // odd row stride: rows start in different LDS banks
+    char *guard = smem + (size_t)kTileSide * ((kTileSide / 2) | 1) * 4;
+    lds_guard_fill(guard);
     for (int w = tid; w < W * Hs; w += blockDim.x) win[w] = 0u;
     if (tid == 0) next_ray = 0;
     __syncthreads();
@@ -869,6 +874,7 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
             if (p1) atomicAdd(&pass[gbase + 2 * d + 1], p1);
         }
     }
+    lds_guard_check(guard, g.status);
 }
 
 size_t tile_scratch_bytes(long rays, long groups)
@@ -912,7 +918,7 @@ hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const
     ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
     hipLaunchKernelGGL((k_ray_bits<ReplaySource>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
     const int tiles_x = (g.xw + kTileSide - 1) / kTileSide, tiles_y = (g.yw + kTileSide - 1) / kTileSide;
-    size_t lds = (size_t)kTileSide * ((kTileSide / 2) | 1) * 4;
+    size_t lds = (size_t)kTileSide * ((kTileSide / 2) | 1) * 4 + kLdsGuard;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_cast),

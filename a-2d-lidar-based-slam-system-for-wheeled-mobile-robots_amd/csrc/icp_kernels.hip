@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
     Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
     double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][5][kMaxWaves]
+    char *guard = smem + nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
+    lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
@@ -403,6 +405,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         if (a.iters_out) a.iters_out[b] = iters;
         if (a.err_out) a.err_out[b] = mean_error;
     }
+    lds_guard_check(guard, a.status);
 }
 
 static inline int icp_block(int n_src, int qpt)
@@ -420,7 +423,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 #define SLAM_ICP_QPT_PREF 3
 #endif
     if (qpt < SLAM_ICP_QPT_PREF && a.n_src > 64 * SLAM_ICP_QPT_PREF) qpt = SLAM_ICP_QPT_PREF;   // queries per lane: fewer waves per pair, cheaper reductions (measured: 3 beats 2 by 3.5 % when replays overlap, 2 beats 1 by 8 % alone)
-    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double);
+    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + kLdsGuard;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q)                                                                                        \

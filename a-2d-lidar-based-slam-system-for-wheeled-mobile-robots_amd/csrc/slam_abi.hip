@@ -216,6 +216,7 @@ int grid_on_main(slam_ctx *c)
 
 int status_to_code(int st)
 {
+    if (st & kStatusGuard) return fail(SLAM_ERR_HIP, "internal: a kernel wrote past its LDS regions (SLAM_LDS_GUARD build)");
     if (st & kStatusNaN) return fail(SLAM_ERR_NAN, "cannot convert float NaN to integer (mapping.py:33-36)");
     if (st & kStatusOverflow)
         return fail(SLAM_ERR_OVERFLOW, "cannot convert float infinity to integer / cell index beyond 2^20 (mapping.py:33-36)");
@@ -506,6 +507,7 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     a.ppt = 0;
     a.B = B; a.n_tar = n_tar; a.n_src = n_src; a.max_iter = max_iter; a.tol = tol;
     a.T_out = T_out; a.iters_out = iters_out; a.err_out = mean_err_out;
+    a.status = c->status;
     Timed t(c, SLAM_K_ICP);
     HIPCHK(launch_icp(a, dtype, c->stream));
     return SLAM_OK;
@@ -960,6 +962,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         a.ppt = n_scan - 1;
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
+        a.status = c->status;
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }
@@ -1056,6 +1059,7 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         a.ppt = 0;
         a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
+        a.status = c->status;
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }

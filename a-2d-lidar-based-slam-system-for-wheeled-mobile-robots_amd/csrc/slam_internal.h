@@ -35,7 +35,32 @@ constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;            // 1024-thread workgroups
 constexpr int kMaxRayCells = 1 << 20;    // longest ray the grid kernels will walk (cells)
 
-enum : int { kStatusNaN = 1, kStatusOverflow = 2 };
+enum : int { kStatusNaN = 1, kStatusOverflow = 2, kStatusGuard = 4 };
+
+// Debug build (-DSLAM_LDS_GUARD, `make guard`): every kernel with dynamic LDS gets kLdsGuard
+// extra bytes behind its last region, fills them with a pattern and checks them before it
+// exits; a changed word raises kStatusGuard (SLAM_ERR_HIP from slam_check_status).  GPU
+// AddressSanitizer is not available on the target pool; this catches the overrun class that
+// matters here (a region sized too small, e.g. a window row count rounded the wrong way).
+#ifdef SLAM_LDS_GUARD
+constexpr int kLdsGuard = 1024;
+#else
+constexpr int kLdsGuard = 0;
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_guard_fill(char *p)
+{
+    for (int i = threadIdx.x; i < kLdsGuard / 4; i += blockDim.x) reinterpret_cast<unsigned *>(p)[i] = 0xA5A5A5A5u;
+}
+__device__ __forceinline__ void lds_guard_check(const char *p, int *status)
+{
+    if (kLdsGuard == 0) return;
+    __syncthreads();
+    bool bad = false;
+    for (int i = threadIdx.x; i < kLdsGuard / 4; i += blockDim.x) bad |= reinterpret_cast<const unsigned *>(p)[i] != 0xA5A5A5A5u;
+    if (bad && status) atomicOr(status, kStatusGuard);
+}
+#endif
 
 // ---- ICP ---------------------------------------------------------------------------
 struct IcpArgs {
@@ -55,6 +80,7 @@ struct IcpArgs {
     double *T_out;             // [B][9]
     int32_t *iters_out;        // nullable [B]
     double *err_out;           // nullable [B]
+    int *status = nullptr;     // sticky status word of the context (LDS guard builds)
 };
 
 hipError_t launch_icp(const IcpArgs &a, int dtype, hipStream_t s);
