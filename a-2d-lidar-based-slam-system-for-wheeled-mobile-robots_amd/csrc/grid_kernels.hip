@@ -889,12 +889,10 @@ bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj)
     return !got && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= 8192;
 }
 
-hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
-                                    const double *poses, const double *centres, int L, int n_scan, int n, int group,
-                                    void *scratch, hipStream_t s)
+template <class Src>
+static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s)
 {
-    if (n_scan < 2) return hipSuccess;
-    const int scans = n_scan - 1;
+    if (scans < 1) return hipSuccess;
     int G = group > 0 ? group : 8;
     G = std::min(G, std::max(1, 65535 / n));
     G = std::min(G, scans);
@@ -915,8 +913,7 @@ hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const
     g_launch_ev = {nullptr, nullptr};
     if (ev.e0) (void)hipEventRecord(ev.e0, s);
     hipLaunchKernelGGL(k_tile_init, dim3((groups + 255) / 256), dim3(256), 0, s, ts.gbox, (int)groups);
-    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
-    hipLaunchKernelGGL((k_ray_bits<ReplaySource>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
+    hipLaunchKernelGGL((k_ray_bits<Src>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
     const int tiles_x = (g.xw + kTileSide - 1) / kTileSide, tiles_y = (g.yw + kTileSide - 1) / kTileSide;
     size_t lds = (size_t)kTileSide * ((kTileSide / 2) | 1) * 4 + kLdsGuard;
     static bool attr_done = false;
@@ -931,6 +928,23 @@ hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const
     hipLaunchKernelGGL(k_tile_cast, dim3(tiles_x * tiles_y, (unsigned)groups), dim3(1024), lds, s, g, ts, tiles_x, G * n, rays);
     if (ev.e1) (void)hipEventRecord(ev.e1, s);
     return hipGetLastError();
+}
+
+hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
+                                    const double *poses, const double *centres, int L, int n_scan, int n, int group,
+                                    void *scratch, hipStream_t s)
+{
+    if (n_scan < 2) return hipSuccess;
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
+    return launch_tiles(g, src, L, n_scan - 1, n, group, scratch, s);
+}
+
+// explicit world-frame endpoints (Mapping.update's own arguments), B scans into one map
+hipError_t launch_grid_update_tiles_explicit(const GridDev &g, const double *ox, const double *oy, const double *cx,
+                                             const double *cy, int B, int n, int group, void *scratch, hipStream_t s)
+{
+    ExplicitSource src{ox, oy, cx, cy, B, n};
+    return launch_tiles(g, src, 1, B, n, group, scratch, s);
 }
 
 __global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,

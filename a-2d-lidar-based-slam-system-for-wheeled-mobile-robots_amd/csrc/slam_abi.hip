@@ -670,10 +670,16 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     REQUIRE(g && ox && oy && cx && cy, "null pointer");
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
     Timed t(c, SLAM_K_GRID);
-    if (c->grid_mode == 1 && !grid_of_batch)
+    const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || c->grid_mode == 2);
+    if ((c->grid_mode == 1 || c->grid_mode == 2) && tiles_ok) {
+        size_t need = tile_scratch_bytes((long)B * n, B);
+        if (need > c->tiles.cap) TRY(arena_reserve(c, c->tiles, need));
+        HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream));
+    } else if (c->grid_mode != 0 && !grid_of_batch) {
         HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream));
-    else
+    } else {
         HIPCHK(launch_grid_update(g->d, ox, oy, cx, cy, B, n, grid_of_batch, c->stream));
+    }
     return SLAM_OK;
 }
 

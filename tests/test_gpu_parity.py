@@ -631,6 +631,21 @@ def test_tiled_ray_cast_cases(slam, syn):
         o.update(obs[0], obs[1], centres[k][0], centres[k][1])
     p, h = m.counters()
     assert np.array_equal(p, o.pass_cnt) and np.array_equal(h, o.hit_cnt)
+    # (d) explicit world-frame endpoints (Mapping.update's arguments), 7 scans in one call
+    rng = np.random.default_rng(9)
+    cx, cy = rng.uniform(-3, 3, 7), rng.uniform(-3, 3, 7)
+    ang, d = rng.uniform(-np.pi, np.pi, (7, 150)), rng.uniform(0, 14, (7, 150))
+    ox, oy = cx[:, None] + np.cos(ang) * d, cy[:, None] + np.sin(ang) * d
+    ox[2, :9] = np.inf
+    g = slam.DeviceGrid(1, 200, 240, 10.0, 10.0, 12.0, context=ctx)
+    g.update_host(ox, oy, cx, cy)
+    og = co.Grid(200, 240, 10.0, 10.0, 12.0)
+    for b in range(7):
+        og.update(ox[b], oy[b], cx[b], cy[b])
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap)
+    assert g.visits() == og.visits
+    g.close()
     ctx.close()
 
 
