@@ -285,8 +285,23 @@ def main():
         from oracle import c_oracle as co
         s = round(1.0 / args.reso)
         og = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
-        op, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, max_iter=args.max_iter, tolerance=args.tol,
-                                    threads=os.cpu_count() or 1, mt_grid=True)
+        if args.points == "f64":
+            op, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, max_iter=args.max_iter, tolerance=args.tol,
+                                        threads=os.cpu_count() or 1, mt_grid=True)
+        else:
+            # reduced point storage: scan matching sees the points rounded to that type, the map
+            # is cast from the float64 points (tests/test_gpu_parity.py::test_replay_reduced_storage_vs_oracle)
+            npdt = {"f32": np.float32, "f16": np.float16}[args.points]
+            pts64 = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges])
+            pts = pts64.astype(npdt).astype(np.float64)
+            oT, oit, _ = co.icp_batch(pts[:-1], pts[1:], args.max_iter, args.tol)
+            op, sta, ov = np.empty((len(oT), 3)), [0.0, 0.0, 0.0], 0
+            for k in range(len(oT)):
+                sta = co.compose_pose(sta, oT[k])
+                op[k] = sta
+                wx, wy = co.world_points(op[k], pts64[k + 1][0], pts64[k + 1][1])
+                og.update(wx, wy, op[k][0], op[k][1])
+            ov = og.visits
         cnt = grid.read(0, want=("pass", "hit"))
         out["parity"] = {"pose_max_abs_err": float(np.max(np.abs(poses[0] - op))), "iters_equal": bool(np.array_equal(iters[0], oit)),
                          "pmap_cell_mismatches": int(np.sum(pmap.cpu().numpy() != og.pmap)),

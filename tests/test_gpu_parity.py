@@ -260,6 +260,32 @@ def test_icp_reduced_storage_matches_oracle_on_rounded_points(slam, syn, dtype, 
     assert np.array_equal(dev, pts[0])
 
 
+@pytest.mark.parametrize("dtype,npdt", [("f32", np.float32), ("f16", np.float16)])
+def test_replay_reduced_storage_vs_oracle(slam, syn, dtype, npdt):
+    """The fused replay with f32 / f16 point storage (BASELINE configs[1] says fp32, configs[4]
+    fp16): scan matching sees the points rounded to that type (formed in registers, never
+    stored), the map is still cast from float64 world points."""
+    rep = syn.make_replay(25, 360, seed=14, stride=5)
+    grid = slam.DeviceGrid.metric(1, 400, 400, 0.05)
+    poses, T, it = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, dtype=dtype)
+    pts64 = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges])
+    pts = pts64.astype(npdt).astype(np.float64)
+    oT, oit, _ = co.icp_batch(pts[:-1], pts[1:], 30, 0.001)
+    assert np.array_equal(it, oit) and np.max(np.abs(T - oT.reshape(T.shape))) < FTOL
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    sta = [0.0, 0.0, 0.0]
+    for k in range(24):
+        sta = co.compose_pose(sta, oT[k].reshape(3, 3))
+        assert np.max(np.abs(poses[k] - np.array(sta))) < FTOL
+        wx, wy = co.world_points(poses[k], pts64[k + 1][0], pts64[k + 1][1])     # device poses: same cells as the device
+        og.update(wx, wy, poses[k][0], poses[k][1])
+    r = grid.read(0, want=("pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+    # and the storage type does change the answer (otherwise this test would prove nothing)
+    _, T64, _ = slam.replay_host(rep.ranges, AMIN, AMAX)
+    assert np.max(np.abs(T64 - T)) > 1e-9
+
+
 def test_particle_priors_vs_oracle(slam, syn):
     """cfg3 operator: one scan pair, P perturbed priors (shared target and source)."""
     pair = syn.scan_pair(360, seed=2)
