@@ -18,7 +18,6 @@ world-frame transform and the ray casting on the device.
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 
 import numpy as np

@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, pkg
-from oracle import c_oracle as co
 from oracle import oracle_np as on
 
 pytestmark = pytest.mark.gpu
