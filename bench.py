@@ -96,14 +96,18 @@ def cpu_baseline(rep, args, budget_s):
                       % (rep.ranges.shape[0], reps, t_used)}
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def load_pmc(kernel):
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 --pmc summary, if any."""
     try:
-        d = json.load(open(p)).get(kernel, {})
-        return d.get("hbm_bytes_per_launch"), d.get("source"), d.get("valu_busy_frac")
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(kernel, {})
     except Exception:
-        return None, None, None
+        return {}
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` (+ source, VALU busy share) from that summary."""
+    d = load_pmc(kernel)
+    return d.get("hbm_bytes_per_launch"), d.get("source"), d.get("valu_busy_frac")
 
 
 def main():
@@ -266,6 +270,14 @@ def main():
     roofline["icp_work"] = {"exhaustive_equivalent_distance_evals_per_s": evals / icp_s, "mean_iters": float(iters.mean()),
                             "note": "equivalent brute-force rate; f64 VALU peak is %.1f TFLOP/s (~%.1e evals/s at 6 flop each)"
                                     % (F64_VALU_PEAK_TFLOPS, F64_VALU_PEAK_TFLOPS * 1e12 / 6)}
+    lds_insts = load_pmc("k_icp").get("lds_insts_per_launch")
+    if lds_insts:
+        # SURVEY.md 8d asks for the ICP's LDS rate next to its VALU rate: an upper bound from the
+        # PMC count of wave-level LDS instructions, pricing each as a 64-lane 16-byte read
+        roofline["icp_work"]["lds"] = {"wave_instructions_per_launch": lds_insts,
+                                       "upper_bound_GBps": lds_insts * 1024.0 / icp_s / 1e9,
+                                       "peak_GBps": 256 * 128 * 2.4,      # 256 CUs x 128 B/clk x 2.4 GHz
+                                       "note": "most are per-lane ds_read_b128 of target points; box reads are broadcasts"}
     grid_s = fam["grid"][0] / max(fam["grid"][1], 1) * 1e-3
     roofline["grid_atomics"] = {"cell_visits_per_step": visits, "visits_per_s": visits / grid_s if grid_s else None}
 

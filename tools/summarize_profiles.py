@@ -77,7 +77,8 @@ def main():
             busy = avg("SQ_ACTIVE_INST_VALU") / (32.0 * avg("GRBM_GUI_ACTIVE")) if c.get("GRBM_GUI_ACTIVE") else None
         traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kb_raw": fetch, "write_kb_raw": write,
                       "source": "profiles/%s_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % tag,
-                      "valu_busy_frac": busy, "valu_insts_per_launch": avg("SQ_INSTS_VALU")}
+                      "valu_busy_frac": busy, "valu_insts_per_launch": avg("SQ_INSTS_VALU"),
+                      "lds_insts_per_launch": avg("SQ_INSTS_LDS")}
         lines.append("%s HBM %.3f MB VALU busy %s" % (k, hbm / 1e6, "n/a" if busy is None else "%.1f %%" % (100 * busy)))
     open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
