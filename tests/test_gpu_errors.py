@@ -1,0 +1,79 @@
+"""Argument validation and error reporting of the C ABI on a live context: every rejected call
+returns SLAM_ERR_INVALID with a message, touches nothing, and leaves the context usable."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    slam = pkg()
+    ctx = slam.Context(0)
+    return slam, slam._abi, slam._abi.lib(), ctx
+
+
+def test_invalid_arguments_are_rejected(env):
+    slam, A, L, ctx = env
+    h = ctx.handle
+    d = np.zeros(64)
+    f = np.zeros(64, dtype=np.float32)
+    i8 = np.zeros(64, dtype=np.int8)
+    k = C.c_int(0)
+    g = slam.DeviceGrid(1, 8, 8, 10.0, 0.4, 0.4, context=ctx)
+    bad = [
+        L.slam_icp_batch(h, None, A.ptr(d), 1, 4, 4, A.F64, 0, 0, None, 5, 1e-3, A.ptr(d), None, None),
+        L.slam_icp_batch(h, A.ptr(d), A.ptr(d), 0, 4, 4, A.F64, 0, 0, None, 5, 1e-3, A.ptr(d), None, None),
+        L.slam_icp_batch(h, A.ptr(d), A.ptr(d), 1, 4, 4, 99, 0, 0, None, 5, 1e-3, A.ptr(d), None, None),
+        L.slam_icp_batch(h, A.ptr(d), A.ptr(d), 1, 4, 4, A.F64, 0, 0, None, -1, 1e-3, A.ptr(d), None, None),
+        L.slam_nn(h, A.ptr(d), A.ptr(d), 1, 0, 4, A.F64, A.ptr(d), A.ptr(np.zeros(4, dtype=np.int32))),
+        L.slam_kabsch2d(h, A.ptr(d), None, 1, 4, A.ptr(d)),
+        L.slam_scan_to_points(h, A.ptr(f), A.ptr(d), A.ptr(d), 1, 0, 1, A.F64, A.ptr(d)),
+        L.slam_pose_compose(h, A.ptr(d), A.ptr(d), 0, 1, A.ptr(d)),
+        L.slam_grid_update(h, g._h, A.ptr(d), A.ptr(d), A.ptr(d), A.ptr(d), 0, 4, None),
+        L.slam_grid_update(h, g._h, A.ptr(d), A.ptr(d), A.ptr(d), A.ptr(d), 1, 4, A.ptr(np.array([3], dtype=np.int32))),
+        L.slam_grid_update_scans(h, g._h, A.ptr(f), A.ptr(d), A.ptr(d), None, None, 1, 4),
+        L.slam_grid_update_scans(h, g._h, A.ptr(f), A.ptr(d), A.ptr(d), A.ptr(d), None, 1, 70000),
+        L.slam_grid_read(h, g._h, 5, A.ptr(i8), None, None, None),
+        L.slam_grid_live_pmap(h, g._h, None),
+        L.slam_grid_counters_dev(h, None, None, None),
+        L.slam_map_obstacles(h, A.ptr(i8), 0, 8, 1, 0.1, 0.0, 0.0, A.ptr(d), A.ptr(d), 8, C.byref(k)),
+        L.slam_virtual_scan(h, A.ptr(d), A.ptr(d), 4, A.ptr(d), 1, 0.0, 0.0, 8, A.ptr(d)),          # zero angle increment
+        L.slam_virtual_scan(h, A.ptr(d), A.ptr(d), 4, A.ptr(d), 0, 0.0, 0.1, 8, A.ptr(d)),
+        L.slam_scan_to_points_f64(h, None, A.ptr(d), A.ptr(d), 1, 4, A.ptr(d)),
+        L.slam_map_observation(h, A.ptr(d), A.ptr(d), 4, A.ptr(d), None, 1, 8, 1, A.ptr(d), A.ptr(d), 0.0, 0.1, 5, 1e-3, A.ptr(d), None),
+        L.slam_replay(h, A.ptr(f), A.ptr(d), A.ptr(d), 1, 1, 8, A.F64, 5, 1e-3, A.ptr(d), None, None, A.ptr(d), None, None),   # n_scan < 2
+        L.slam_particles(h, A.ptr(f), A.ptr(d), A.ptr(d), 8, A.F64, None, A.ptr(d), 0, 5, 1e-3, None, A.ptr(d), A.ptr(d), None),
+        L.slam_set_option(h, b"no_such_option", 1.0),
+        L.slam_set_option(h, b"grid_mode", 7.0),
+        L.slam_bresenham_batch(h, None, None, 1, None, None, None, 0),
+    ]
+    assert all(rc == A.ERR_INVALID for rc in bad), bad
+    assert L.slam_last_error()                                   # a message is kept
+    hh = C.c_void_p()
+    assert L.slam_grid_create(h, 1, 4, 4, 10.0, 0.2, 0.2, 0.01, 1.0, 10.0, C.byref(hh)) == A.ERR_INVALID   # 8 hits cannot exceed thresh
+    assert L.slam_grid_create(h, 0, 4, 4, 10.0, 0.2, 0.2, 0.01, 20.0, 10.0, C.byref(hh)) == A.ERR_INVALID
+    # nothing above touched the map, and the context still works
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.all(r["pmap"] == 50) and r["pass"].sum() == 0 and r["hit"].sum() == 0
+    ctx.check_status()
+    T, it, _ = slam.icp_batch_host(np.random.default_rng(0).normal(size=(2, 40)), np.random.default_rng(1).normal(size=(2, 40)),
+                                   5, 0.0, context=ctx)
+    assert it[0] == 5 and np.isfinite(T).all()
+
+
+def test_python_layer_maps_error_codes(env):
+    slam, A, L, ctx = env
+    with pytest.raises(slam.SlamError):
+        ctx.set_option("grid_group", 1000)
+    m = slam.Mapping(200, 200, 0.1, context=ctx)
+    with pytest.raises(ValueError):                               # int(nan) in the reference
+        m.update([float("nan")], [0.0], 0.0, 0.0)
+    with pytest.raises(OverflowError):                            # int(inf)
+        m.update([0.0], [float("inf")], 0.0, 0.0)
+    m.update([0.5], [0.5], 0.0, 0.0)                              # the sticky flag was cleared
+    assert m.pmap.max() == 100
