@@ -138,6 +138,40 @@ def mapobs(slam, torch, B, steps, warmup):
             "virtual_scan_algorithmic_GBps": (B * K * 16 + B * n * 8) / dt_vs / 1e9}
 
 
+def dropin(slam, torch, steps):
+    """Latency of the drop-in classes, one scan per call as a rospy callback makes them (host
+    pointers in and out, synchronous): what a user of the reference's API sees."""
+    rep = slam.synthetic.make_replay(steps + 2, 360, seed=1, stride=5)
+    icp = slam.ICP()
+    clouds = [icp.laserToNumpy(rep.message(k)) for k in range(steps + 2)]
+
+    def wall(fn, n):
+        fn(0)
+        t0 = time.perf_counter()
+        for k in range(n):
+            fn(k)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    t_proc = wall(lambda k: icp.process(clouds[k], clouds[k + 1]), steps)
+    m = slam.Mapping.metric(400, 400, 0.05)
+    ang = np.linspace(AMIN, AMAX, 360)
+    pts = [(np.cos(ang) * rep.ranges[k], np.sin(ang) * rep.ranges[k]) for k in range(steps + 1)]
+    t_map = wall(lambda k: m.update(pts[k][0], pts[k][1], 0.0, 0.0), steps)
+    node = slam.SLAM_EKF()
+    node.laser_count = 4
+    msgs = [rep.message(k) for k in range(steps + 2)]
+
+    def cb(k):
+        node.laser_count = 4          # process every message
+        node.laserCallback(msgs[k + 1])
+    t_node = wall(cb, steps)
+    t_l2n = wall(lambda k: icp.laserToNumpy(msgs[k]), steps)
+    return {"config": "drop-in classes, one 360-beam scan per call (host pointers, synchronous)",
+            "ICP.process_ms": t_proc, "Mapping.update_ms": t_map, "SLAM_EKF.laserCallback_ms": t_node,
+            "ICP.laserToNumpy_ms": t_l2n, "unit": "ms per call",
+            "reference_as_written_ms": {"ICP.process": 1840.0, "Mapping.update": 16.9, "note": "SURVEY.md section 6 (360 beams, this container's CPU)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="particles,dense,long")
@@ -154,6 +188,8 @@ def main():
             out = particles(slam, torch, args.particles, args.steps, args.warmup, live=True)
         elif w == "particles_nolive":
             out = particles(slam, torch, args.particles, args.steps, args.warmup, live=False)
+        elif w == "dropin":
+            out = dropin(slam, torch, 200)
         elif w == "mapobs":
             out = mapobs(slam, torch, 4096, args.steps, args.warmup)
         elif w == "dense":
