@@ -14,15 +14,19 @@ are the ones effective in the W12 mapping node, max_iter 30 / tolerance 1e-3
 (float32 ranges) already resident in HBM: map reset -> 999 ICP solves (polar->Cartesian
 fused in) -> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of `value`: processed
 scans per second (one ICP.process + one Mapping.update each), summed over all ranks.
+Consecutive steps are independent replays, so they are dealt round-robin to --lanes contexts
+(own stream, map and output buffers; default 4) and overlap on the chip; nothing of a step is
+skipped or shared, and --check compares the last step of a run with the CPU oracle bit for bit
+(cells, counters, iteration counts) / to 1e-9 (poses).  ms_per_step = elapsed / K.
 
 With N > 1 every rank replays its own trajectory (seed 1 + rank; weak scaling, no
 data-path collective); the ranks' final poses (3 float64 per replay) are exchanged with RCCL
 all_gather, the only exchange BASELINE.json configs[3] has: one collective for all K
-replays at the end of the timed region (--gather end, default) or one asynchronous
-all_gather per replay (--gather step).
+replays at the end of the timed region (--gather end, default) or one all_gather per
+replay (--gather step).
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside the
-library on the launch stream) and "cpu_baseline" (oracle/slam_oracle.c, the C port of the
+Extra objects on the JSON line: "roofline" (dominant kernel, timed inside the library with
+HIP events carried by every dispatch on its launch stream) and "cpu_baseline" (oracle/slam_oracle.c, the C port of the
 reference, on this host's cores; rank 0, N = 1 only).
 """
 from __future__ import annotations
