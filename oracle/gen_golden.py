@@ -457,6 +457,17 @@ def gen_g5(ref, out_dir):
         T = node.calc_map_observation(m)
         Ts.append(T), srcs.append(r), xests.append(guess)
     arrays.update(obs_wall=wall, obs_T=np.array(Ts), obs_ranges=np.array(srcs), obs_xest=np.array(xests))
+    # the 3-state pose filter of the node (W9/ekf.py, pure NumPy: loaded as it is) over a short sequence
+    ekf9 = _load_asis("ekf_w9", os.path.join(W9, "ekf.py")).EKF()
+    x, P = np.array([0.1, -0.2, 0.05]), np.eye(3)
+    xs, Ps, zs, Tm = [], [], [], []
+    for k in range(8):
+        th = rng.normal(0, 0.05)
+        T = np.array([[np.cos(th), -np.sin(th), rng.normal(0.05, 0.01)], [np.sin(th), np.cos(th), rng.normal(0, 0.01)], [0, 0, 1.0]])
+        z = ekf9.odom_model(x, T) + rng.normal(0, [0.02, 0.02, 0.01])
+        x, P = ekf9.estimate(x, P, z, T)
+        xs.append(np.array(x, dtype=float)), Ps.append(np.array(P)), zs.append(np.array(z, dtype=float)), Tm.append(T)
+    arrays.update(ekf9_x=np.array(xs), ekf9_P=np.array(Ps), ekf9_z=np.array(zs), ekf9_T=np.array(Tm))
     save(out_dir, "g5_map_observation.npz", **arrays)
 
 

@@ -81,3 +81,14 @@ def test_ekf_quirks():
     # a known landmark is matched (no growth) and the yaw is wrapped at the end
     x3, P3 = ekf.estimate(x2.copy(), P2.copy(), np.array([[2.0, 0.1, 0]]), np.zeros((3, 1)))
     assert len(x3) == 5 and -np.pi <= x3[2, 0] < np.pi
+
+
+def test_w9_pose_filter_golden():
+    """localization.EKF (the 3-state filter of the W9 node) against the reference's own ekf.py."""
+    g5 = load_golden("g5_map_observation.npz")
+    ekf = pkg("localization").EKF()
+    x, P = np.array([0.1, -0.2, 0.05]), np.eye(3)
+    for k in range(g5["ekf9_x"].shape[0]):
+        x, P = ekf.estimate(x, P, g5["ekf9_z"][k], g5["ekf9_T"][k])
+        assert np.max(np.abs(np.asarray(x, dtype=float) - g5["ekf9_x"][k])) < 1e-12, k
+        assert np.max(np.abs(P - g5["ekf9_P"][k])) < 1e-12, k
