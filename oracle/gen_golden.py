@@ -468,6 +468,31 @@ def gen_g5(ref, out_dir):
         x, P = ekf9.estimate(x, P, z, T)
         xs.append(np.array(x, dtype=float)), Ps.append(np.array(P)), zs.append(np.array(z, dtype=float)), Tm.append(T)
     arrays.update(ekf9_x=np.array(xs), ekf9_P=np.array(Ps), ekf9_z=np.array(zs), ekf9_T=np.array(Tm))
+    # the whole node: a second copy of localization.py bound to the REAL ekf.py, fed a 36-message
+    # stream (6 processed scans: odometry ICP twice, map observation, filter)
+    stub = sys.modules["ekf"]
+    sys.modules["ekf"] = sys.modules["ekf_w9"]
+    try:
+        full_mod = _load_py2("localization_full", os.path.join(W9, "localization.py"))
+    finally:
+        sys.modules["ekf"] = stub
+    with quiet():
+        full = full_mod.Localization()
+    full.publishResult = lambda *a, **k: None
+    full.obstacle = wall
+    empty = syn.World(5.0, 4.0, (), 0.0)
+    traj = np.stack([0.2 + 0.01 * np.arange(36), -0.1 + 0.004 * np.arange(36), 0.05 + 0.004 * np.arange(36)], axis=1)
+    stream = syn.scans_from_poses(empty, traj, 120, 75)
+    xe, xo, steps = [], [], []
+    for k in range(36):
+        before = (np.array(full.xEst, dtype=float).copy(), np.array(full.xOdom, dtype=float).copy())
+        m = syn.LaserScan(ranges=tuple(float(v) for v in stream[k]), angle_increment=(syn.ANGLE_MAX - syn.ANGLE_MIN) / 119)
+        with quiet():
+            full.laserCallback(m)
+        if not np.array_equal(before[1], np.array(full.xOdom, dtype=float)):
+            steps.append(k); xe.append(np.array(full.xEst, dtype=float)); xo.append(np.array(full.xOdom, dtype=float))
+    arrays.update(node9_ranges=stream, node9_steps=np.array(steps), node9_xest=np.array(xe), node9_xodom=np.array(xo),
+                  node9_P=np.array(full.PEst))
     save(out_dir, "g5_map_observation.npz", **arrays)
 
 

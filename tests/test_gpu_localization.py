@@ -169,3 +169,19 @@ def test_localization_callback_sequence(slam, g5, syn):
         assert np.max(np.abs(np.asarray(loc.xEst) - xest)) < 1e-9, k
         assert np.max(np.abs(np.asarray(loc.xOdom) - xodom)) < 1e-9, k
         assert np.max(np.abs(loc.PEst - pest)) < 1e-9
+
+
+def test_w9_node_golden(slam, g5):
+    """Localization.laserCallback on the reference's own run of the whole W9 node (real ekf.py):
+    6 processed scans, each = odometry ICP (twice, as the reference does) + map observation +
+    pose filter."""
+    loc = slam.Localization()
+    loc.obstacle = g5["obs_wall"]
+    steps = {int(k): i for i, k in enumerate(g5["node9_steps"])}
+    for k, r in enumerate(g5["node9_ranges"]):
+        loc.laserCallback(scan_msg(slam, r, 120))
+        if k in steps:
+            i = steps[k]
+            assert np.max(np.abs(np.asarray(loc.xEst, dtype=float) - g5["node9_xest"][i])) < 1e-9, k
+            assert np.max(np.abs(np.asarray(loc.xOdom, dtype=float) - g5["node9_xodom"][i])) < 1e-9, k
+    assert np.max(np.abs(loc.PEst - g5["node9_P"])) < 1e-9 and len(steps) == 6
