@@ -18,7 +18,12 @@ seeded synthetic inputs, and only the inputs and outputs are written out.
                           laserToNumpy / calc_odometry / T2u / u2T (EKF and landmark
                           extraction are stubbed: out of scope).
 
-Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,g2,g3,g4]
+      W12o/mapping.py     as O2 (the +4 variant, G6).
+      W9/localization.py  as O4; W9/ekf.py loaded as it is (pure NumPy) - G5: updateMap,
+                          laserEstimation, calc_map_observation, the pose filter and the whole
+                          Localization.laserCallback.
+
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,...,g7]
 """
 from __future__ import annotations
 
