@@ -71,6 +71,8 @@ struct slam_ctx {
     Arena staging;   // device copies of host arguments (host-pointer entry points)
     Arena scratch;   // temporaries of *_dev sequences
     Arena tiles;     // recorded walks of the tiled ray cast
+    char *pinned = nullptr;   // page-locked host block: small calls go through it in one copy each way
+    size_t pinned_cap = 0;
     int *status = nullptr;
     bool timing = false;
     std::vector<hipEvent_t> pool;
@@ -206,6 +208,20 @@ int join_from_grid(slam_ctx *c)
     return SLAM_OK;
 }
 
+constexpr size_t kPinnedBytes = 256 * 1024;
+
+bool ensure_pinned(slam_ctx *c)
+{
+    if (c->pinned) return true;
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->pinned), kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+        c->pinned = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    c->pinned_cap = kPinnedBytes;
+    return true;
+}
+
 // entry points that touch a map on the MAIN stream call this first
 int grid_on_main(slam_ctx *c)
 {
@@ -311,6 +327,7 @@ int slam_destroy(slam_ctx *c)
     if (c->staging.base) (void)hipFree(c->staging.base);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     if (c->tiles.base) (void)hipFree(c->tiles.base);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->status) (void)hipFree(c->status);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -530,6 +547,27 @@ int slam_icp_batch(slam_ctx *c, const void *tar, const void *src, int B, int n_t
     double *d_T = carve<double>(c->staging, (size_t)B * 9);
     int32_t *d_i = carve<int32_t>(c->staging, B);
     double *d_e = carve<double>(c->staging, B);
+    REQUIRE(d_t && d_s && d_T && d_i && d_e && (!prior || d_p), "workspace");
+    // Small calls (the drop-in ICP.process: one pair, ~12 KB in, 84 B out) are latency bound:
+    // inputs and outputs each cross in ONE copy through a page-locked block laid out like the
+    // device staging area, instead of five pageable copies.
+    const size_t in_span = (size_t)((prior ? reinterpret_cast<char *>(d_p) + (size_t)B * 48 : d_s + bs) - d_t);
+    const size_t out_span = (size_t)(reinterpret_cast<char *>(d_e) + (size_t)B * 8 - reinterpret_cast<char *>(d_T));
+    const bool packed = in_span + out_span <= kPinnedBytes && ensure_pinned(c);
+    if (packed) {
+        char *h_in = c->pinned, *h_out = c->pinned + in_span;
+        memcpy(h_in, tar, bt);
+        memcpy(h_in + (d_s - d_t), src, bs);
+        if (prior) memcpy(h_in + (reinterpret_cast<char *>(d_p) - d_t), prior, (size_t)B * 48);
+        H2D(d_t, h_in, in_span);
+        TRY(slam_icp_batch_dev(c, d_t, d_s, B, n_tar, n_src, dtype, tar_shared, src_shared, d_p, max_iter, tol, d_T, d_i, d_e));
+        D2H(h_out, d_T, out_span);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(T_out, h_out, (size_t)B * 72);
+        if (iters_out) memcpy(iters_out, h_out + (reinterpret_cast<char *>(d_i) - reinterpret_cast<char *>(d_T)), (size_t)B * 4);
+        if (mean_err_out) memcpy(mean_err_out, h_out + (reinterpret_cast<char *>(d_e) - reinterpret_cast<char *>(d_T)), (size_t)B * 8);
+        return SLAM_OK;
+    }
     H2D(d_t, tar, bt);
     H2D(d_s, src, bs);
     if (prior) H2D(d_p, prior, (size_t)B * 48);
@@ -696,11 +734,24 @@ int slam_grid_update(slam_ctx *c, slam_grid *g, const double *ox, const double *
     double *d_x = carve<double>(c->staging, np), *d_y = carve<double>(c->staging, np);
     double *d_cx = carve<double>(c->staging, B), *d_cy = carve<double>(c->staging, B);
     int32_t *d_g = grid_of_batch ? carve<int32_t>(c->staging, B) : nullptr;
-    H2D(d_x, ox, np * 8);
-    H2D(d_y, oy, np * 8);
-    H2D(d_cx, cx, (size_t)B * 8);
-    H2D(d_cy, cy, (size_t)B * 8);
-    if (grid_of_batch) H2D(d_g, grid_of_batch, (size_t)B * 4);
+    REQUIRE(d_x && d_y && d_cx && d_cy && (!grid_of_batch || d_g), "workspace");
+    const size_t span = (size_t)((d_g ? reinterpret_cast<char *>(d_g) + (size_t)B * 4 : reinterpret_cast<char *>(d_cy) + (size_t)B * 8) -
+                                 reinterpret_cast<char *>(d_x));
+    if (span <= kPinnedBytes && ensure_pinned(c)) {      // one scan of Mapping.update: one copy instead of four
+        char *h = c->pinned, *base = reinterpret_cast<char *>(d_x);
+        memcpy(h, ox, np * 8);
+        memcpy(h + (reinterpret_cast<char *>(d_y) - base), oy, np * 8);
+        memcpy(h + (reinterpret_cast<char *>(d_cx) - base), cx, (size_t)B * 8);
+        memcpy(h + (reinterpret_cast<char *>(d_cy) - base), cy, (size_t)B * 8);
+        if (d_g) memcpy(h + (reinterpret_cast<char *>(d_g) - base), grid_of_batch, (size_t)B * 4);
+        H2D(d_x, h, span);
+    } else {
+        H2D(d_x, ox, np * 8);
+        H2D(d_y, oy, np * 8);
+        H2D(d_cx, cx, (size_t)B * 8);
+        H2D(d_cy, cy, (size_t)B * 8);
+        if (grid_of_batch) H2D(d_g, grid_of_batch, (size_t)B * 4);
+    }
     TRY(slam_grid_update_dev(c, g, d_x, d_y, d_cx, d_cy, B, n, d_g));
     return check_status_sync(c);
 }

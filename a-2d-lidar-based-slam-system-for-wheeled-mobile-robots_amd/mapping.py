@@ -41,7 +41,8 @@ class Mapping:
         self.xw = int(xw)
         self.yw = int(yw)
         self.pmap = 50 * np.ones((self.xw, self.yw))   # default 50: unknown (mapping.py:14)
-        self.datamap = np.zeros((self.xw, self.yw))    # mapping.py:15
+        self._datamap = np.zeros((self.xw, self.yw))   # mapping.py:15, fetched on demand (see ``datamap``)
+        self._datamap_stale = False
         self.minx = -self.width_x / 2.0
         self.maxx = self.width_x / 2.0
         self.miny = -self.width_y / 2.0
@@ -56,6 +57,24 @@ class Mapping:
                                                float(hit_inc), float(thresh), C.byref(h)))
         self._grid = h
         self._p8 = np.empty((self.xw, self.yw), dtype=np.int8)
+        # one scan per call owns the map: the ray cast keeps pmap current on the device itself
+        live = C.c_void_p()
+        _abi.check(_abi.lib().slam_grid_live_pmap(self._ctx.handle, self._grid, C.byref(live)))
+
+    @property
+    def datamap(self):
+        """The evidence map of mapping.py:15 (float64 [xw, yw]).  ``update`` only brings ``pmap``
+        back from the device; this view (8 bytes per cell) is read when it is asked for."""
+        if self._datamap_stale:
+            _abi.check(_abi.lib().slam_grid_read(self._ctx.handle, self._grid, 0, None, _abi.ptr(self._datamap), None, None))
+            self._datamap_stale = False
+        return self._datamap
+
+    def _fetch_pmap(self):
+        _abi.check(_abi.lib().slam_grid_read(self._ctx.handle, self._grid, 0, _abi.ptr(self._p8), None, None, None))
+        self.pmap[...] = self._p8
+        self._datamap_stale = True
+        return self.pmap
 
     @classmethod
     def metric(cls, xw, yw, xyreso, **kw):
@@ -84,12 +103,12 @@ class Mapping:
         cx = np.array([float(np.asarray(center_x).reshape(-1)[0])])
         cy = np.array([float(np.asarray(center_y).reshape(-1)[0])])
         L = _abi.lib()
-        _abi.check(L.slam_grid_update(self._ctx.handle, self._grid, _abi.ptr(ox), _abi.ptr(oy), _abi.ptr(cx),
-                                      _abi.ptr(cy), 1, n, None))
-        _abi.check(L.slam_grid_read(self._ctx.handle, self._grid, 0, _abi.ptr(self._p8), _abi.ptr(self.datamap),
-                                    None, None))
-        self.pmap[...] = self._p8
-        return self.pmap
+        try:
+            _abi.check(L.slam_grid_update(self._ctx.handle, self._grid, _abi.ptr(ox), _abi.ptr(oy), _abi.ptr(cx),
+                                          _abi.ptr(cy), 1, n, None))
+        finally:
+            self._datamap_stale = True            # on a NaN / inf beam the other beams were still applied
+        return self._fetch_pmap()
 
     def update_scans(self, ranges, angle_min, angle_max, poses, centres=None):
         """S raw scans at once (``slam_grid_update_scans``): ranges [S, n] (inf -> 30 m), poses
@@ -104,12 +123,12 @@ class Mapping:
         c = None if centres is None else np.ascontiguousarray(np.asarray(centres, dtype=np.float64).reshape(S, 2))
         ct, st = _abi.trig_tables(angle_min, angle_max, n)
         L = _abi.lib()
-        _abi.check(L.slam_grid_update_scans(self._ctx.handle, self._grid, _abi.ptr(r), _abi.ptr(ct), _abi.ptr(st),
-                                            _abi.ptr(p), _abi.ptr(c), S, n))
-        _abi.check(L.slam_grid_read(self._ctx.handle, self._grid, 0, _abi.ptr(self._p8), _abi.ptr(self.datamap),
-                                    None, None))
-        self.pmap[...] = self._p8
-        return self.pmap
+        try:
+            _abi.check(L.slam_grid_update_scans(self._ctx.handle, self._grid, _abi.ptr(r), _abi.ptr(ct), _abi.ptr(st),
+                                                _abi.ptr(p), _abi.ptr(c), S, n))
+        finally:
+            self._datamap_stale = True
+        return self._fetch_pmap()
 
     def counters(self):
         """(pass, hit) uint32 [xw, yw]: the integer evidence behind ``datamap``."""

@@ -132,10 +132,7 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
         self.last_u = self.T2u(self.last_T)
         self.xEst[:3, 0] = pose[0]
         self.icp.sensor_sta = [float(v) for v in pose[0]]
-        _abi.check(_abi.lib().slam_grid_read(self._ctx.handle, self.mapping._grid, 0, _abi.ptr(self.mapping._p8),
-                                             _abi.ptr(self.mapping.datamap), None, None))
-        self.mapping.pmap[...] = self.mapping._p8
-        self.publishMap(self.mapping.pmap)                         # :91
+        self.publishMap(self.mapping._fetch_pmap())                # :91
 
     def _landmark_callback(self, msg, ranges):
         """slam_ekf.py:73-95 in full: extraction -> odometry -> EKF -> map from xEst."""
@@ -162,10 +159,7 @@ class SLAM_EKF:  # noqa: N801 (the reference's class name)
             centre = np.array([[float(self.x_online), float(self.y_online)]])
         _abi.check(_abi.lib().slam_grid_update_scans(self._ctx.handle, self.mapping._grid, _abi.ptr(ranges), _abi.ptr(ct),
                                                      _abi.ptr(st), _abi.ptr(pose), _abi.ptr(centre), 1, n))   # :88-90
-        _abi.check(_abi.lib().slam_grid_read(self._ctx.handle, self.mapping._grid, 0, _abi.ptr(self.mapping._p8),
-                                             _abi.ptr(self.mapping.datamap), None, None))
-        self.mapping.pmap[...] = self.mapping._p8
-        self.publishMap(self.mapping.pmap)                         # :91
+        self.publishMap(self.mapping._fetch_pmap())                # :91
 
     def observation(self, lm):
         """slam_ekf.py:96-106: landmarks (sensor frame) -> rows (range, bearing, index)."""
