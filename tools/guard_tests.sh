@@ -6,6 +6,6 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PKG="$R/a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd"
-[ -f "$PKG/libslamhip_guard.so" ] || make -s -C "$PKG/csrc" guard
+make -s -C "$PKG/csrc" guard            # always: the guard library must match the sources
 SLAM_HIP_LIB="$PKG/libslamhip_guard.so" python -m pytest "$R/tests" -m gpu -x -q "$@"
 SLAM_HIP_LIB="$PKG/libslamhip_guard.so" python "$R/bench.py" --no-cpu-baseline --check --steps 8 --warmup 2 | grep -o '"parity.*'
