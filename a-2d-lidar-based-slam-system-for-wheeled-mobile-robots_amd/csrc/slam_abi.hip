@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <initializer_list>
 #include <vector>
 
 #include "slam_internal.h"
@@ -222,6 +223,65 @@ bool ensure_pinned(slam_ctx *c)
     return true;
 }
 
+// Host <-> staging copies of an entry point.  The pieces lie in ONE arena in ascending order, so
+// when they are small (a drop-in call: one scan pair, one scan) they cross the bus in one copy
+// through the page-locked block, laid out like the device pieces; otherwise one copy per piece.
+struct Seg {
+    void *dev;
+    void *host;          // source (copy_in) or destination (copy_out_sync); null pieces are skipped
+    size_t bytes;
+};
+
+int copy_in(slam_ctx *c, std::initializer_list<Seg> segs)
+{
+    char *lo = nullptr, *hi = nullptr;
+    for (const Seg &g : segs) {
+        if (!g.host || !g.bytes) continue;
+        if (!g.dev) return fail(SLAM_ERR_NOMEM, "internal: workspace");
+        char *d = static_cast<char *>(g.dev);
+        if (!lo || d < lo) lo = d;
+        if (!hi || d + g.bytes > hi) hi = d + g.bytes;
+    }
+    if (!lo) return SLAM_OK;
+    const size_t span = (size_t)(hi - lo);
+    if (span <= kPinnedBytes / 2 && ensure_pinned(c)) {
+        for (const Seg &g : segs)
+            if (g.host && g.bytes) memcpy(c->pinned + (static_cast<char *>(g.dev) - lo), g.host, g.bytes);
+        HIPCHK(hipMemcpyAsync(lo, c->pinned, span, hipMemcpyHostToDevice, c->stream));
+        return SLAM_OK;
+    }
+    for (const Seg &g : segs)
+        if (g.host && g.bytes) HIPCHK(hipMemcpyAsync(g.dev, g.host, g.bytes, hipMemcpyHostToDevice, c->stream));
+    return SLAM_OK;
+}
+
+int copy_out_sync(slam_ctx *c, std::initializer_list<Seg> segs)
+{
+    char *lo = nullptr, *hi = nullptr;
+    for (const Seg &g : segs) {
+        if (!g.host || !g.bytes) continue;
+        if (!g.dev) return fail(SLAM_ERR_NOMEM, "internal: workspace");
+        char *d = static_cast<char *>(g.dev);
+        if (!lo || d < lo) lo = d;
+        if (!hi || d + g.bytes > hi) hi = d + g.bytes;
+    }
+    if (lo) {
+        const size_t span = (size_t)(hi - lo);
+        if (span <= kPinnedBytes / 2 && ensure_pinned(c)) {
+            char *h = c->pinned + kPinnedBytes / 2;
+            HIPCHK(hipMemcpyAsync(h, lo, span, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (const Seg &g : segs)
+                if (g.host && g.bytes) memcpy(g.host, h + (static_cast<char *>(g.dev) - lo), g.bytes);
+            return SLAM_OK;
+        }
+        for (const Seg &g : segs)
+            if (g.host && g.bytes) HIPCHK(hipMemcpyAsync(g.host, g.dev, g.bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
 // entry points that touch a map on the MAIN stream call this first
 int grid_on_main(slam_ctx *c)
 {
@@ -434,13 +494,10 @@ int slam_scan_to_points(slam_ctx *c, const float *ranges, const double *cos_t, c
     float *d_r = carve<float>(c->staging, nr);
     double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
     char *d_p = carve<char>(c->staging, 2 * nr * ds);
-    H2D(d_r, ranges, nr * 4);
-    H2D(d_c, cos_t, (size_t)n * 8);
-    H2D(d_s, sin_t, (size_t)n * 8);
+    TRY(copy_in(c, {{d_r, const_cast<float *>(ranges), nr * 4}, {d_c, const_cast<double *>(cos_t), (size_t)n * 8},
+                    {d_s, const_cast<double *>(sin_t), (size_t)n * 8}}));
     TRY(slam_scan_to_points_dev(c, d_r, d_c, d_s, B, n, clip_inf, dtype, d_p));
-    D2H(pts_out, d_p, 2 * nr * ds);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return SLAM_OK;
+    return copy_out_sync(c, {{d_p, pts_out, 2 * nr * ds}});
 }
 
 int slam_nn_dev(slam_ctx *c, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype, double *dist,
@@ -547,36 +604,10 @@ int slam_icp_batch(slam_ctx *c, const void *tar, const void *src, int B, int n_t
     double *d_T = carve<double>(c->staging, (size_t)B * 9);
     int32_t *d_i = carve<int32_t>(c->staging, B);
     double *d_e = carve<double>(c->staging, B);
-    REQUIRE(d_t && d_s && d_T && d_i && d_e && (!prior || d_p), "workspace");
-    // Small calls (the drop-in ICP.process: one pair, ~12 KB in, 84 B out) are latency bound:
-    // inputs and outputs each cross in ONE copy through a page-locked block laid out like the
-    // device staging area, instead of five pageable copies.
-    const size_t in_span = (size_t)((prior ? reinterpret_cast<char *>(d_p) + (size_t)B * 48 : d_s + bs) - d_t);
-    const size_t out_span = (size_t)(reinterpret_cast<char *>(d_e) + (size_t)B * 8 - reinterpret_cast<char *>(d_T));
-    const bool packed = in_span + out_span <= kPinnedBytes && ensure_pinned(c);
-    if (packed) {
-        char *h_in = c->pinned, *h_out = c->pinned + in_span;
-        memcpy(h_in, tar, bt);
-        memcpy(h_in + (d_s - d_t), src, bs);
-        if (prior) memcpy(h_in + (reinterpret_cast<char *>(d_p) - d_t), prior, (size_t)B * 48);
-        H2D(d_t, h_in, in_span);
-        TRY(slam_icp_batch_dev(c, d_t, d_s, B, n_tar, n_src, dtype, tar_shared, src_shared, d_p, max_iter, tol, d_T, d_i, d_e));
-        D2H(h_out, d_T, out_span);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        memcpy(T_out, h_out, (size_t)B * 72);
-        if (iters_out) memcpy(iters_out, h_out + (reinterpret_cast<char *>(d_i) - reinterpret_cast<char *>(d_T)), (size_t)B * 4);
-        if (mean_err_out) memcpy(mean_err_out, h_out + (reinterpret_cast<char *>(d_e) - reinterpret_cast<char *>(d_T)), (size_t)B * 8);
-        return SLAM_OK;
-    }
-    H2D(d_t, tar, bt);
-    H2D(d_s, src, bs);
-    if (prior) H2D(d_p, prior, (size_t)B * 48);
+    TRY(copy_in(c, {{d_t, const_cast<void *>(tar), bt}, {d_s, const_cast<void *>(src), bs},
+                    {d_p, const_cast<double *>(prior), prior ? (size_t)B * 48 : 0}}));
     TRY(slam_icp_batch_dev(c, d_t, d_s, B, n_tar, n_src, dtype, tar_shared, src_shared, d_p, max_iter, tol, d_T, d_i, d_e));
-    D2H(T_out, d_T, (size_t)B * 72);
-    if (iters_out) D2H(iters_out, d_i, (size_t)B * 4);
-    if (mean_err_out) D2H(mean_err_out, d_e, (size_t)B * 8);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return SLAM_OK;
+    return copy_out_sync(c, {{d_T, T_out, (size_t)B * 72}, {d_i, iters_out, (size_t)B * 4}, {d_e, mean_err_out, (size_t)B * 8}});
 }
 
 int slam_pose_compose_dev(slam_ctx *c, const double *T, const double *pose0, int L, int n, double *poses_out)
@@ -734,24 +765,9 @@ int slam_grid_update(slam_ctx *c, slam_grid *g, const double *ox, const double *
     double *d_x = carve<double>(c->staging, np), *d_y = carve<double>(c->staging, np);
     double *d_cx = carve<double>(c->staging, B), *d_cy = carve<double>(c->staging, B);
     int32_t *d_g = grid_of_batch ? carve<int32_t>(c->staging, B) : nullptr;
-    REQUIRE(d_x && d_y && d_cx && d_cy && (!grid_of_batch || d_g), "workspace");
-    const size_t span = (size_t)((d_g ? reinterpret_cast<char *>(d_g) + (size_t)B * 4 : reinterpret_cast<char *>(d_cy) + (size_t)B * 8) -
-                                 reinterpret_cast<char *>(d_x));
-    if (span <= kPinnedBytes && ensure_pinned(c)) {      // one scan of Mapping.update: one copy instead of four
-        char *h = c->pinned, *base = reinterpret_cast<char *>(d_x);
-        memcpy(h, ox, np * 8);
-        memcpy(h + (reinterpret_cast<char *>(d_y) - base), oy, np * 8);
-        memcpy(h + (reinterpret_cast<char *>(d_cx) - base), cx, (size_t)B * 8);
-        memcpy(h + (reinterpret_cast<char *>(d_cy) - base), cy, (size_t)B * 8);
-        if (d_g) memcpy(h + (reinterpret_cast<char *>(d_g) - base), grid_of_batch, (size_t)B * 4);
-        H2D(d_x, h, span);
-    } else {
-        H2D(d_x, ox, np * 8);
-        H2D(d_y, oy, np * 8);
-        H2D(d_cx, cx, (size_t)B * 8);
-        H2D(d_cy, cy, (size_t)B * 8);
-        if (grid_of_batch) H2D(d_g, grid_of_batch, (size_t)B * 4);
-    }
+    TRY(copy_in(c, {{d_x, const_cast<double *>(ox), np * 8}, {d_y, const_cast<double *>(oy), np * 8},
+                    {d_cx, const_cast<double *>(cx), (size_t)B * 8}, {d_cy, const_cast<double *>(cy), (size_t)B * 8},
+                    {d_g, const_cast<int32_t *>(grid_of_batch), grid_of_batch ? (size_t)B * 4 : 0}}));
     TRY(slam_grid_update_dev(c, g, d_x, d_y, d_cx, d_cy, B, n, d_g));
     return check_status_sync(c);
 }
@@ -1070,24 +1086,19 @@ int slam_replay(slam_ctx *c, const float *ranges, const double *cos_t, const dou
         for (int l = 0; l < L; ++l) REQUIRE(grid_of_traj[l] >= 0 && grid_of_traj[l] < grid->d.G, "grid_of_traj out of range");
     size_t nr = (size_t)L * n_scan * n, pairs = (size_t)L * (n_scan - 1);
     TRY(arena_reserve(c, c->staging, align_up(nr * 4) + 2 * align_up((size_t)n * 8) + align_up((size_t)L * 24) +
-                                         align_up(2 * nr * ds) + align_up(pairs * 72) + align_up(pairs * 24) +
-                                         align_up(pairs * 4) + align_up((size_t)L * 4) + 4096));
+                                         align_up(pairs * 72) + align_up(pairs * 24) + align_up(pairs * 4) +
+                                         align_up((size_t)L * 4) + 4096));
     float *d_r = carve<float>(c->staging, nr);
     double *d_c = carve<double>(c->staging, n), *d_s = carve<double>(c->staging, n);
     double *d_0 = carve<double>(c->staging, (size_t)L * 3);
-    char *d_pts = carve<char>(c->staging, 2 * nr * ds);
+    int32_t *d_g = (grid && grid_of_traj) ? carve<int32_t>(c->staging, L) : nullptr;
     double *d_T = carve<double>(c->staging, pairs * 9), *d_P = carve<double>(c->staging, pairs * 3);
     int32_t *d_it = carve<int32_t>(c->staging, pairs);
-    int32_t *d_g = (grid && grid_of_traj) ? carve<int32_t>(c->staging, L) : nullptr;
-    H2D(d_r, ranges, nr * 4);
-    H2D(d_c, cos_t, (size_t)n * 8);
-    H2D(d_s, sin_t, (size_t)n * 8);
-    H2D(d_0, pose0, (size_t)L * 24);
-    if (d_g) H2D(d_g, grid_of_traj, (size_t)L * 4);
-    TRY(slam_replay_dev(c, d_r, d_c, d_s, L, n_scan, n, dtype, max_iter, tol, d_0, grid, d_g, d_pts, d_P, d_T, d_it));
-    D2H(poses_out, d_P, pairs * 24);
-    if (T_out) D2H(T_out, d_T, pairs * 72);
-    if (iters_out) D2H(iters_out, d_it, pairs * 4);
+    TRY(copy_in(c, {{d_r, const_cast<float *>(ranges), nr * 4}, {d_c, const_cast<double *>(cos_t), (size_t)n * 8},
+                    {d_s, const_cast<double *>(sin_t), (size_t)n * 8}, {d_0, const_cast<double *>(pose0), (size_t)L * 24},
+                    {d_g, const_cast<int32_t *>(grid_of_traj), d_g ? (size_t)L * 4 : 0}}));
+    TRY(slam_replay_dev(c, d_r, d_c, d_s, L, n_scan, n, dtype, max_iter, tol, d_0, grid, d_g, nullptr, d_P, d_T, d_it));
+    TRY(copy_out_sync(c, {{d_P, poses_out, pairs * 24}, {d_T, T_out, pairs * 72}, {d_it, iters_out, pairs * 4}}));
     return check_status_sync(c);
 }
 
