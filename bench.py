@@ -124,7 +124,7 @@ def main():
     # Each lane's stream should own a hardware queue (the HIP runtime multiplexes streams onto
     # GPU_MAX_HW_QUEUES queues, 4 by default): with a process group RCCL adds streams of its own,
     # and two lanes sharing a queue serialise (measured 0.26 instead of 0.18 ms per step).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     dist = None
     # under torch.distributed.run (RANK and MASTER_ADDR set) the collective path is taken even
