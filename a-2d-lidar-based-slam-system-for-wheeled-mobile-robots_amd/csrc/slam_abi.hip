@@ -926,8 +926,14 @@ int slam_grid_occupancy_data(slam_ctx *c, slam_grid *g, int gi, int8_t *data)
     size_t per = (size_t)g->d.xw * g->d.yw;
     TRY(arena_reserve(c, c->scratch, align_up(per) + 1024));
     int8_t *d_data = carve<int8_t>(c->scratch, per);
-    HIPCHK(launch_grid_finalize(g->d, gi, 1, g->pmap_one, c->stream));
-    HIPCHK(launch_grid_transpose(g->pmap_one, g->d.xw, g->d.yw, d_data, c->stream));
+    const int8_t *pm = g->pmap_one;
+    if (g->pmap_live) {                       // kept current by the ray casts: no finalize pass
+        TRY(refresh_live(c, g, c->stream));
+        pm = g->pmap_live + per * gi;
+    } else {
+        HIPCHK(launch_grid_finalize(g->d, gi, 1, g->pmap_one, c->stream));
+    }
+    HIPCHK(launch_grid_transpose(pm, g->d.xw, g->d.yw, d_data, c->stream));
     D2H(data, d_data, per);
     HIPCHK(hipStreamSynchronize(c->stream));
     return SLAM_OK;
