@@ -478,6 +478,14 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
                 covers = 0;
             }
+            // the window is W rows of (H + 1) / 2 dwords: it must fit the kWinCells 16-bit cells carved
+            // for it.  Should the sizing above ever be wrong again (it once used the unpadded height: a
+            // 193 x 191 box wrote 96 dwords past the window), fall back to no window at all - every cell
+            // then takes the direct-atomic path, still exact - and raise the internal-error status bit.
+            if ((long)W * ((H + 1) >> 1) > kWinCells / 2) {
+                atomicOr(g.status, kStatusGuard);
+                W = 0; H = 0; covers = 0;
+            }
         }
         box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers;
     }

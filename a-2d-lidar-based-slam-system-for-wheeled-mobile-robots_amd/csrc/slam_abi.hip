@@ -1104,6 +1104,10 @@ int slam_replay(slam_ctx *c, const float *ranges, const double *cos_t, const dou
                     {d_s, const_cast<double *>(sin_t), (size_t)n * 8}, {d_0, const_cast<double *>(pose0), (size_t)L * 24},
                     {d_g, const_cast<int32_t *>(grid_of_traj), d_g ? (size_t)L * 4 : 0}}));
     TRY(slam_replay_dev(c, d_r, d_c, d_s, L, n_scan, n, dtype, max_iter, tol, d_0, grid, d_g, nullptr, d_P, d_T, d_it));
+    // "pipeline" option with a map: compose ran on cstream and the ray cast on gstream (which
+    // waited for compose): the copies below are issued on the main stream, which must first see
+    // both (join_from_grid records on gstream, i.e. after ev_pose of cstream).
+    TRY(join_from_grid(c));
     TRY(copy_out_sync(c, {{d_P, poses_out, pairs * 24}, {d_T, T_out, pairs * 72}, {d_it, iters_out, pairs * 4}}));
     return check_status_sync(c);
 }

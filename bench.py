@@ -1,40 +1,51 @@
 #!/usr/bin/env python3
-"""bench.py - scans/s of the ICP + occupancy-grid hot path on MI355X.
+"""bench.py - throughput of the ICP + occupancy-grid hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK /
-  WORLD_SIZE / MASTER_* from the environment).  Rank 0 prints ONE JSON line.
+  N > 1 without WORLD_SIZE in the environment: this process (which has not imported torch or
+  touched HIP) starts the N ranks itself as `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`, lets rank 0's JSON
+  line through and exits with the children's status.  Launched BY torch.distributed.run (RANK /
+  LOCAL_RANK / WORLD_SIZE / MASTER_* set) it is one rank per GPU; WORLD_SIZE must equal --gpus.
+  Rank 0 prints ONE JSON line.
 
-Workload = BASELINE.json configs[1]: a 1k-scan replay, 360 beams, ICP.process +
-Mapping.update per scan into a 400x400 @ 0.05 m grid.  "1k scans" are 1000 PROCESSED
-scans: every 5th message of a 10 Hz stream, as the reference's callback decimates
-(W12m/slam_ekf.py:65-68), so consecutive processed scans are 0.5 s apart.  ICP parameters
-are the ones effective in the W12 mapping node, max_iter 30 / tolerance 1e-3
-(W12m/icp.py:21-25).  One "step" = one pass of the hot path over that batch, inputs
-(float32 ranges) already resident in HBM: map reset -> 999 ICP solves (polar->Cartesian
-fused in) -> pose composition -> 999 x 360 rays cast -> pmap finalize.  Unit of `value`: processed
-scans per second (one ICP.process + one Mapping.update each), summed over all ranks.
-Consecutive steps are independent replays, so they are dealt round-robin to --lanes contexts
-(own stream, map and output buffers; default 4) and overlap on the chip; nothing of a step is
-skipped or shared, and --check compares the last step of a run with the CPU oracle bit for bit
-(cells, counters, iteration counts) / to 1e-9 (poses).  ms_per_step = elapsed / K.
+--config selects the BASELINE.json configuration (all print the same JSON shape with "roofline",
+"cpu_baseline" and an in-run "parity" block against the C oracle):
+  replay     (default) configs[1]: a 1k-scan replay, 360 beams, ICP.process + Mapping.update per
+             scan into a 400x400 @ 0.05 m grid.  With N > 1: configs[3], one 5k-scan trajectory
+             per GPU (seed 10 + rank), final poses exchanged with one RCCL all_gather.
+  particles  configs[2]: 10 000 prior hypotheses of one 360-beam scan pair, one 400x400 @ 0.05 m
+             map per particle (maps persist across steps, as in a particle filter).
+  dense      configs[4]: 1k-scan replay, 1080 beams, 2000x2000 @ 0.02 m grid, fp16 point buffers.
 
-With N > 1 every rank replays its own trajectory (seed 1 + rank; weak scaling, no
-data-path collective); the ranks' final poses (3 float64 per replay) are exchanged with RCCL
-all_gather, the only exchange BASELINE.json configs[3] has: one collective for all K
-replays at the end of the timed region (--gather end, default) or one all_gather per
-replay (--gather step).
+"1k scans" are 1000 PROCESSED scans: every 5th message of a 10 Hz stream, as the reference's
+callback decimates (W12m/slam_ekf.py:65-68).  ICP parameters are the ones effective in the W12
+mapping node, max_iter 30 / tolerance 1e-3 (W12m/icp.py:21-25).  One "step" = one pass of the hot
+path over that batch, inputs (float32 ranges) already resident in HBM:
+  replay / dense: map reset -> n-1 ICP solves (polar->Cartesian fused in) -> pose composition ->
+                  (n-1) x beams rays cast -> pmap finalize;
+  particles:      P ICP solves on the prior-perturbed scan -> P pose steps -> P x 360 rays cast
+                  into P maps with pmap kept current (no reset: the maps accumulate).
+Unit of `value`: processed scans per second (one ICP.process + one Mapping.update each; for
+particles one per hypothesis), summed over all ranks.  Consecutive steps are independent, so in
+the replay config they are dealt round-robin to --lanes contexts (own stream, map and output
+buffers; default 4) and overlap on the chip; nothing of a step is skipped or shared.
+ms_per_step = elapsed / K.  "single_stream" repeats the measurement with ONE lane (kernels back
+to back: per-kernel times there satisfy kernel time <= step time); "sustained" keeps stepping
+the same workload until >= 0.5 s have passed.
 
-Extra objects on the JSON line: "roofline" (dominant kernel, timed inside the library with
-HIP events carried by every dispatch on its launch stream) and "cpu_baseline" (oracle/slam_oracle.c, the C port of the
-reference, on this host's cores; rank 0, N = 1 only).
+Extra objects on the JSON line: "roofline" (dominant kernel; durations from HIP events carried
+by every dispatch on its launch stream), "cpu_baseline" (oracle/slam_oracle.c, the C port of the
+reference, on this host's cores; rank 0, N = 1 only) and "parity" (the last step's results
+against the oracle: cells / counters / iteration counts exact, poses to 1e-9).
 """
 from __future__ import annotations
 
 import argparse
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,85 +57,329 @@ PKG = "a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector (half the 157.3 TF FP32 vector rate)
+# f64 VALU issue: 256 CUs x 4 SIMDs, one wave64 f64 instruction per 4 cycles per SIMD at 2.4 GHz
+F64_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
 AMIN, AMAX = -3.14159, 3.14159
+
+CONFIGS = {
+    # name: scans, beams, grid, reso, room_scale, points, seed, lanes
+    "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=4),
+    "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=1),
+    "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=1),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scans", type=int, default=1000)
-    ap.add_argument("--beams", type=int, default=360)
-    ap.add_argument("--grid", type=int, default=400)
-    ap.add_argument("--reso", type=float, default=0.05)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50; 10 for particles / dense)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="replay", choices=sorted(CONFIGS))
+    ap.add_argument("--scans", type=int, default=None, help="processed scans per trajectory (default 1000; 5000 with --gpus > 1)")
+    ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--beams", type=int, default=None)
+    ap.add_argument("--grid", type=int, default=None)
+    ap.add_argument("--reso", type=float, default=None)
     ap.add_argument("--stride", type=int, default=5)
-    ap.add_argument("--room-scale", type=float, default=1.0)
+    ap.add_argument("--room-scale", type=float, default=None)
     ap.add_argument("--max-iter", type=int, default=30)
     ap.add_argument("--tol", type=float, default=1e-3)
-    ap.add_argument("--points", default="f64", choices=["f64", "f32", "f16"],
+    ap.add_argument("--points", default=None, choices=["f64", "f32", "f16"],
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
-    ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window here; tiles on maps much larger than a window), 0: direct global atomics, 2: tiles, 3: window")
+    ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window; tiles on maps much larger than a window), 0: direct global atomics, 2: tiles, 3: window")
     ap.add_argument("--grid-group", type=int, default=-1,
-                    help="scans per ray-cast workgroup (0: the library's choice, 8 here; default: 12 when replays overlap "
-                         "(measured 0.177 ms per step against 0.187 with 8), else 0)")
+                    help="scans per ray-cast workgroup (0: the library's choice; default: 12 when replays overlap, else 0)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
-    ap.add_argument("--time-lane0-only", action="store_true", help="HIP events on lane 0 only (default: every lane)")
-    ap.add_argument("--lanes", type=int, default=4, help="contexts (stream sets) the replays alternate between")
+    ap.add_argument("--lanes", type=int, default=None, help="contexts (stream sets) the replays alternate between")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1: map stage of a replay on a second stream, overlapping the next replay's scan matching")
     ap.add_argument("--gather", default="end", choices=["step", "end", "none"],
                     help="N > 1: all_gather of final poses after every replay (async), once at the end, or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check", action="store_true", help="also compare the GPU result with the oracle")
-    return ap.parse_args()
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run comparison with the oracle")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the one-lane repeat of the measurement")
+    ap.add_argument("--sustain-seconds", type=float, default=0.5)
+    ap.add_argument("--check", action="store_true", help="(kept for compatibility: the parity block is always on)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    if args.scans is None:
+        # configs[3] (N > 1) names 5k-scan trajectories, configs[1] / [4] a 1k-scan replay
+        args.scans = 5000 if (args.gpus > 1 and args.config == "replay") else cfg["scans"]
+    if args.steps is None:
+        args.steps = 50 if args.config == "replay" else 10
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "replay" else 2
+    if args.grid_group < 0:
+        args.grid_group = 12 if (args.lanes > 1 and args.config == "replay") else 0
+    return args
 
 
-def cpu_baseline(rep, args, budget_s):
-    """The C port of the reference (oracle/slam_oracle.c, orc_replay_mt: ICP solves and ray
-    casting under OpenMP) on this host, same replay, repeated until ~budget_s seconds."""
-    from oracle import c_oracle as co
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    s = round(1.0 / args.reso)
+def spawn_ranks(args):
+    """--gpus N > 1 outside torch.distributed.run: start the ranks as child processes.  Nothing
+    in this process has imported torch or initialised HIP; it only waits and relays the status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------
+# CPU baselines (the C port of the reference on this host's cores), bounded samples
+# --------------------------------------------------------------------------------------
+def cpu_threads():
+    return max(1, min(os.cpu_count() or 1, 64))
+
+
+def cpu_baseline_replay(rep, args, budget_s):
+    """orc_replay_mt (ICP solves and ray casting under OpenMP) on a bounded sample of the same
+    replay, repeated until ~budget_s seconds."""
+    from oracle import checks
+    threads = cpu_threads()
+    # a sample the host finishes in seconds: the whole 360-beam replay, the first scans of a dense one
+    n = rep.ranges.shape[0] if args.beams <= 400 else min(rep.ranges.shape[0], 120)
+    n = min(n, 1000)
+    sample = rep.ranges[:n]
     reps, t_used = 0, 0.0
     while reps < 1 or (t_used < budget_s and reps < 40):
-        g = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
+        g = checks.metric_grid(args.grid, args.grid, args.reso)
         t0 = time.perf_counter()
-        co.replay(rep.ranges, AMIN, AMAX, g, max_iter=args.max_iter, tolerance=args.tol, threads=threads, mt_grid=True)
+        checks.replay_reference(sample, AMIN, AMAX, g, args.points, args.max_iter, args.tol, threads=threads)
         t_used += time.perf_counter() - t0
         reps += 1
-    scans = (rep.ranges.shape[0] - 1) * reps
-    return {"value": scans / t_used, "unit": "scans/s", "cores": threads, "kind": "port",
-            "sample": "full %d-scan replay x %d repeats (%.1f s), C port of the reference, OpenMP over scan pairs and rays"
-                      % (rep.ranges.shape[0], reps, t_used)}
+    return {"value": (n - 1) * reps / t_used, "unit": "scans/s", "cores": threads, "kind": "port",
+            "sample": "first %d scans of the %d-scan replay x %d repeats (%.1f s), C port of the reference, OpenMP over scan pairs%s"
+                      % (n, rep.ranges.shape[0], reps, t_used, " and rays" if args.points == "f64" else "; map cast sequentially")}
 
 
-def load_pmc(kernel):
-    """Per-launch PMC figures of `kernel` from the committed rocprofv3 --pmc summary, if any."""
+def cpu_baseline_particles(wl, args, budget_s):
+    """Particle hypotheses one by one through the C port (ICP.process on the perturbed source, pose
+    step, Mapping.update into a fresh map), a thread per particle (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import checks
+    threads = cpu_threads()
+    done, t_used = 0, 0.0
+    r0, r1 = wl.rep.ranges[0], wl.rep.ranges[1]
+
+    def one(p):
+        checks.particle_reference(r0, r1, AMIN, AMAX, wl.mats[p], wl.pose_prev[p], args.grid, args.grid, args.reso,
+                                  args.max_iter, args.tol)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        while done < wl.P and (done == 0 or t_used < budget_s):
+            batch = range(done, min(wl.P, done + 8 * threads))
+            t0 = time.perf_counter()
+            list(ex.map(one, batch))
+            t_used += time.perf_counter() - t0
+            done += len(batch)
+    return {"value": done / t_used, "unit": "scans/s", "cores": threads, "kind": "port",
+            "sample": "first %d of %d particle hypotheses (%.1f s), C port of the reference, one thread per particle" % (done, wl.P, t_used)}
+
+
+def load_pmc(config, kernel):
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 --pmc summaries, if any
+    (profiles/pmc_traffic.json: {config: {kernel: {...}}}; produced by tools/profile_gpu.sh)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(kernel, {})
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return {}
+    d = d.get(config, d if config == "replay" else {})
+    return d.get(kernel, {}) if isinstance(d, dict) else {}
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch of `kernel` (+ source, VALU busy share) from that summary."""
-    d = load_pmc(kernel)
-    return d.get("hbm_bytes_per_launch"), d.get("source"), d.get("valu_busy_frac")
+# --------------------------------------------------------------------------------------
+# workloads
+# --------------------------------------------------------------------------------------
+class ReplayWorkload:
+    """configs[1] / [3] / [4]: per lane a DeviceReplay + map + pmap; a step runs on lane slot % lanes."""
+    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
+
+    def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
+        self.slam, self.torch, self.args = slam, torch, args
+        seed = (10 + rank) if args.gpus > 1 and args.config == "replay" else CONFIGS[args.config]["seed"] + rank
+        self.rep = slam.synthetic.make_replay(args.scans, args.beams, seed=seed, room_scale=args.room_scale, stride=args.stride)
+        self.seed = seed
+
+        class Lane:
+            pass
+        self.lanes = []
+        for _ in range(max(1, n_lanes)):
+            ln = Lane()
+            ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
+            with torch.cuda.stream(ln.stream):
+                ln.dr = slam.DeviceReplay(self.rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
+                                          dtype=args.points, device=local)
+                ln.grid = ln.dr.make_grid(1, args.grid, args.grid, args.reso)
+                ln.pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
+                ln.ring_T = torch.empty((2,) + tuple(ln.dr.T.shape), dtype=torch.float64, device=ln.dr.dev)
+            ln.dr.ctx.set_option("grid_mode", args.grid_mode)
+            ln.dr.ctx.set_option("grid_group", args.grid_group if n_lanes > 1 or args.grid_group != 12 else 0)
+            ln.dr.ctx.set_option("pipeline", args.pipeline)
+            ln.count = 0
+            self.lanes.append(ln)
+        self.dev = self.lanes[0].dr.dev
+        self.ring = torch.empty((slots,) + tuple(self.lanes[0].dr.poses.shape), dtype=torch.float64, device=self.dev)
+        self.done = 0
+        self.L = slam._abi.lib()
+        self.units_per_step = self.lanes[0].dr.scans_per_run
+        if self.tiled():
+            self.family_kernels = dict(self.family_kernels, grid="k_tile_cast")
+
+    def tiled(self):
+        a = self.args
+        return a.grid_mode == 2 or (a.grid_mode == 1 and a.grid * a.grid > 8 * 36864)
+
+    def contexts(self):
+        return [ln.dr.ctx for ln in self.lanes]
+
+    def step(self):
+        slot = self.done
+        self.done += 1
+        ln = self.lanes[slot % len(self.lanes)]
+        ln.dr.run(reset_grid=True, poses_out=self.ring[slot % self.ring.shape[0]], T_out=ln.ring_T[ln.count & 1])
+        ln.count += 1
+        self.slam._abi.check(self.L.slam_grid_finalize_dev(ln.dr.ctx.handle, ln.grid._h, ln.pmap.data_ptr()))
+        return ln, slot
+
+    def last_lane(self):
+        return self.lanes[(self.done - 1) % len(self.lanes)]
+
+    def final_poses(self, slots):
+        return self.ring[:slots, 0, -1, :].contiguous().reshape(-1)
+
+    def collect(self):
+        ln = self.last_lane()
+        poses, T, iters = ln.dr.results()
+        self.iters = iters
+        self.visits = ln.grid.visits()          # in-bounds cell visits of the last step (reset every step)
+        dev = {"poses": poses[0], "T": T[0], "iters": iters[0], "visits": self.visits, "pmap": ln.pmap.cpu().numpy()}
+        dev.update(ln.grid.read(0, want=("pass", "hit")))
+        return dev
+
+    def parity(self, dev):
+        from oracle import checks
+        a = self.args
+        return checks.compare_replay(dev, self.rep.ranges, AMIN, AMAX, a.grid, a.grid, a.reso, a.points, a.max_iter, a.tol,
+                                     threads=cpu_threads())
+
+    def algorithmic_bytes(self):
+        a = self.args
+        n = self.units_per_step
+        # SURVEY 8(d) prices a pair at (n_src+n_tar)*2*s + 72 B for point buffers of s bytes per coordinate.
+        # polar->Cartesian is fused into k_icp: the kernel reads the raw float32 ranges instead (4 B per
+        # point) and no point buffer exists: (n_src+n_tar)*4 + 72 B per pair.  Grid: 9 B per in-bounds
+        # cell visit (4 B counter read + 4 B write + 1 B pmap).
+        return {"icp": n * ((2 * a.beams) * 4 + 72), "grid": 9 * self.visits, "compose": n * (72 + 24),
+                "finalize": a.grid * a.grid * 9}
+
+    def workload_name(self):
+        a = self.args
+        which = "configs[3] share" if a.gpus > 1 and a.config == "replay" else ("configs[4]" if a.config == "dense" else "configs[1]")
+        return ("%s: %d-scan replay (every %dth message of a 10 Hz stream, seed %d), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid, %s point buffers"
+                % (which, a.scans, a.stride, self.seed, a.beams, a.max_iter, a.tol, a.grid, a.grid, a.reso, a.points))
+
+    def cpu_baseline(self, budget):
+        return cpu_baseline_replay(self.rep, self.args, budget)
+
+
+class ParticleWorkload:
+    """configs[2]: slam_particles_dev on P hypotheses; maps persist (no reset), live pmap."""
+    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
+
+    def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
+        self.slam, self.torch, self.args = slam, torch, args
+        A = slam._abi
+        self.dev = torch.device("cuda", local)
+        torch.cuda.set_device(self.dev)
+        self.ctx = A.Context(local, torch.cuda.current_stream(self.dev).cuda_stream)
+        P = self.P = args.particles
+        self.rep = slam.synthetic.make_replay(2, args.beams, seed=2 + rank, stride=args.stride)
+        n = args.beams
+        ct, st = A.trig_tables(AMIN, AMAX, n)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.mats = slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2 + rank))
+        self.pose_prev = np.random.default_rng(4 + rank).normal(0, 0.5, size=(P, 3))
+        self.t = dict(ranges2=d(self.rep.ranges.astype(np.float32)), cos_t=d(ct), sin_t=d(st), prior=d(self.mats.reshape(P, 6)),
+                      pose_prev=d(self.pose_prev), poses=torch.empty((P, 3), dtype=torch.float64, device=self.dev),
+                      T=torch.empty((P, 9), dtype=torch.float64, device=self.dev),
+                      iters=torch.empty(P, dtype=torch.int32, device=self.dev))
+        self.grid = slam.DeviceGrid.metric(P, args.grid, args.grid, args.reso, context=self.ctx)
+        self.pmap_ptr = self.grid.live_pmap()
+        self.ring = torch.empty((slots, 3), dtype=torch.float64, device=self.dev)
+        self.L = A.lib()
+        self.done = 0
+        self.units_per_step = P
+
+    def contexts(self):
+        return [self.ctx]
+
+    def step(self):
+        A, t, a = self.slam._abi, self.t, self.args
+        A.check(self.L.slam_particles_dev(self.ctx.handle, t["ranges2"].data_ptr(), t["cos_t"].data_ptr(), t["sin_t"].data_ptr(),
+                                          a.beams, A.DTYPES[a.points], t["prior"].data_ptr(), t["pose_prev"].data_ptr(), self.P,
+                                          a.max_iter, a.tol, self.grid._h, None, t["poses"].data_ptr(), t["T"].data_ptr(),
+                                          t["iters"].data_ptr()))
+        A.check(self.L.slam_grid_finalize_dev(self.ctx.handle, self.grid._h, self.pmap_ptr))
+        self.done += 1
+        return None, self.done - 1
+
+    def final_poses(self, slots):
+        return self.t["poses"][-1].repeat(slots).contiguous()
+
+    def collect(self):
+        self.ctx.check_status()
+        t = self.t
+        self.iters = t["iters"].cpu().numpy()
+        self.visits = self.grid.visits() / max(self.done, 1)     # per step (the maps are never reset)
+        return {"poses": t["poses"].cpu().numpy(), "T": t["T"].cpu().numpy(), "iters": self.iters}
+
+    def parity(self, dev):
+        from oracle import checks
+        a, P = self.args, self.P
+        rng = np.random.default_rng(7)
+        sample = sorted(set([0, P // 2, P - 1] + rng.integers(0, P, size=21).tolist()))
+        out = checks.compare_particles(dev["poses"], dev["T"], dev["iters"], lambda p: self.grid.read(p, want=("pmap", "pass", "hit")),
+                                       sample, self.rep.ranges[0], self.rep.ranges[1], AMIN, AMAX, self.mats, self.pose_prev,
+                                       a.grid, a.grid, a.reso, a.max_iter, a.tol, steps=self.done)
+        out["map_steps_accumulated"] = self.done
+        return out
+
+    def algorithmic_bytes(self):
+        a = self.args
+        return {"icp": self.P * ((2 * a.beams) * 4 + 72 + 48), "grid": 9 * self.visits, "compose": self.P * (72 + 48 + 24 + 24),
+                "finalize": self.P * a.grid * a.grid * 9}
+
+    def workload_name(self):
+        a = self.args
+        return ("configs[2]: %d particle hypotheses (perturbed priors) of one %d-beam scan pair, ICP(max_iter=%d, tol=%g) + one %dx%d@%.2fm map per particle (persistent, live pmap)"
+                % (self.P, a.beams, a.max_iter, a.tol, a.grid, a.grid, a.reso))
+
+    def cpu_baseline(self, budget):
+        return cpu_baseline_particles(self, self.args, budget)
 
 
 def main():
     args = parse()
-    if args.grid_group < 0:
-        args.grid_group = 12 if args.lanes > 1 else 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or unset WORLD_SIZE and "
+              "let bench.py start the ranks)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
     # Each lane's stream should own a hardware queue (the HIP runtime multiplexes streams onto
     # GPU_MAX_HW_QUEUES queues, 4 by default): with a process group RCCL adds streams of its own,
     # and two lanes sharing a queue serialise (measured 0.26 instead of 0.18 ms per step).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import importlib
     import torch
     dist = None
     # under torch.distributed.run (RANK and MASTER_ADDR set) the collective path is taken even
@@ -134,109 +389,74 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     slam = importlib.import_module(PKG)
+    slots = args.steps + args.warmup
+    Workload = ParticleWorkload if args.config == "particles" else ReplayWorkload
+    wl = Workload(slam, torch, args, rank, local, args.lanes, slots)
+    dev = wl.dev
+    gathered = torch.empty((slots, world * 3), dtype=torch.float64, device=dev) if use_dist else None
+    gathered_all = torch.empty(world * slots * 3, dtype=torch.float64, device=dev) if use_dist else None
+    torch.cuda.synchronize()
 
-    rep = slam.synthetic.make_replay(args.scans, args.beams, seed=1 + rank, room_scale=args.room_scale, stride=args.stride)
-    # Consecutive replays are independent, so they are overlapped two ways (results are
-    # unchanged, see --check):
-    #  * --lanes 4 (default): replays alternate between four contexts (own stream, own map and
-    #    output buffers; the GPU exposes four hardware queues per process), so one replay's
-    #    latency-bound stretches (kernel tails, the ray cast) are filled by the others' work;
-    #  * --pipeline 1: inside a context the library runs scan matching, pose composition and
-    #    the map stage (reset -> ray cast -> finalize) on three HIP streams, so the map stage of
-    #    one replay overlaps the scan matching of the next (4.3 M scans/s with one lane; with
-    #    four lanes the extra streams oversubscribe the hardware queues, hence off by default).
     # Every replay writes its poses into its own slot of a ring (T into one of two buffers per
     # lane).  N > 1: the ranks' final poses are all-gathered (RCCL), the only exchange
     # BASELINE.json configs[3] has; nothing is copied per step and no replay stream ever waits
     # for a collective.
-    #   --gather end  (default): ONE all_gather of all K replays' final poses at the end of
-    #                 the timed region (one larger collective instead of K latency-bound ones);
-    #   --gather step: one all_gather per replay (synchronises the lane first).
-    class Lane:
-        pass
-
-    lanes = []
-    for _ in range(max(1, args.lanes)):
-        ln = Lane()
-        ln.stream = torch.cuda.Stream(device=local) if args.lanes > 1 else torch.cuda.current_stream(local)
-        with torch.cuda.stream(ln.stream):
-            ln.dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
-                                      dtype=args.points, device=local)
-            ln.grid = ln.dr.make_grid(1, args.grid, args.grid, args.reso)
-            ln.pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
-            ln.ring_T = torch.empty((2,) + tuple(ln.dr.T.shape), dtype=torch.float64, device=ln.dr.dev)
-        ln.dr.ctx.set_option("grid_mode", args.grid_mode)
-        ln.dr.ctx.set_option("grid_group", args.grid_group)
-        ln.dr.ctx.set_option("pipeline", args.pipeline)
-        ln.count = 0
-        lanes.append(ln)
-    dr = lanes[0].dr
-    slots = args.steps + args.warmup
-    ring = torch.empty((slots,) + tuple(dr.poses.shape), dtype=torch.float64, device=dr.dev)
-    gathered = torch.empty((slots, world * 3), dtype=torch.float64, device=dr.dev) if use_dist else None
-    gathered_all = torch.empty(world * slots * 3, dtype=torch.float64, device=dr.dev) if use_dist else None
-    torch.cuda.synchronize()
-    done = [0]
-    L = slam._abi.lib()
-
-    def step():
-        slot = done[0]
-        done[0] += 1
-        ln = lanes[slot % len(lanes)]
-        ln.dr.run(reset_grid=True, poses_out=ring[slot], T_out=ln.ring_T[ln.count & 1])
-        ln.count += 1
-        slam._abi.check(L.slam_grid_finalize_dev(ln.dr.ctx.handle, ln.grid._h, ln.pmap.data_ptr()))
-        if use_dist and args.gather == "step":
+    def step(w=wl):
+        ln, slot = w.step()
+        if use_dist and args.gather == "step" and ln is not None:
             ln.dr.ctx.synchronize()
-            dist.all_gather_into_tensor(gathered[slot], ring[slot, 0, -1])
+            dist.all_gather_into_tensor(gathered[slot % slots], w.ring[slot % slots, 0, -1])
 
     marks = {}
 
-    def fence():
-        for ln in lanes:
-            ln.dr.ctx.synchronize()        # joins the lane's compose / map streams
+    def fence(w=wl, collective=True):
+        for c in w.contexts():
+            c.synchronize()                # joins the lane's compose / map streams
         marks["drained"] = time.perf_counter()
-        if use_dist and args.gather == "end":
-            dist.all_gather_into_tensor(gathered_all, ring[:, 0, -1, :].contiguous().reshape(-1))
+        if use_dist and args.gather == "end" and collective:
+            dist.all_gather_into_tensor(gathered_all, w.final_poses(slots))
         torch.cuda.synchronize()
-        if use_dist:
+        if use_dist and collective:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def timed(w, steps, collective=True):
+        """Time exactly `steps` steps of workload w; returns (elapsed, enqueue, {family: [ms, launches]})."""
+        for c in w.contexts():
+            c.timing_enable(not args.no_timing)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(w)
+        enqueue = time.perf_counter() - t0     # host time to enqueue all steps (launch-bound if ~ elapsed)
+        fence(w, collective)
+        elapsed = time.perf_counter() - t0
+        fam = {}
+        for c in w.contexts():                 # HIP-event times per kernel family
+            for k, v in c.timing_read().items():
+                acc = fam.setdefault(k, [0.0, 0])
+                acc[0] += v[0]
+                acc[1] += v[1]
+            c.timing_enable(False)
+        return elapsed, enqueue, fam, t0
 
     for _ in range(args.warmup):
         step()
     fence()
     # HIP events ride on every kernel dispatch of the timed region as its start / stop events
     # (hipExtLaunchKernelGGL inside the library): exact kernel execution times, no queue markers.
-    timed_lanes = lanes[:1] if args.time_lane0_only else lanes
-    for ln in timed_lanes:
-        ln.dr.ctx.timing_enable(not args.no_timing)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    enqueue = time.perf_counter() - t0      # host time to enqueue all steps (launch-bound if ~ elapsed)
-    fence()
-    elapsed = elapsed_local = time.perf_counter() - t0
-    fam = {}
-    for ln in timed_lanes:                 # HIP-event times per kernel family
-        for k, v in ln.dr.ctx.timing_read().items():
-            acc = fam.setdefault(k, [0.0, 0])
-            acc[0] += v[0]
-            acc[1] += v[1]
-        ln.dr.ctx.timing_enable(False)
-    last = lanes[(done[0] - 1) % len(lanes)]
-    dr, grid, pmap = last.dr, last.grid, last.pmap
+    elapsed, enqueue, fam, t0 = timed(wl, args.steps)
+    elapsed_local = elapsed
+    closing_ms = (t0 + elapsed_local - marks["drained"]) * 1e3
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dr.dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    scans_per_step = dr.scans_per_run
-    visits = grid.visits()                 # in-bounds cell visits of the last step (reset every step)
-    poses, T, iters = dr.results()
-    total_scans = scans_per_step * world * args.steps
-    value = total_scans / elapsed
+    n_ranks = dist.get_world_size() if use_dist else 1
+    value = wl.units_per_step * n_ranks * args.steps / elapsed
+    dev_results = wl.collect()
 
     if args.no_timing:
         if rank == 0:
@@ -246,97 +466,109 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- the same workload, run on past the contract's K steps until >= --sustain-seconds ----
+    sustained = None
+    if args.sustain_seconds > 0 and not use_dist:
+        per = elapsed / args.steps
+        more = int(min(max(args.sustain_seconds / per, 1), 200000))
+        for c in wl.contexts():
+            c.timing_enable(False)
+        ts = time.perf_counter()
+        for _ in range(more):
+            step()
+        fence(collective=False)
+        dt = time.perf_counter() - ts
+        sustained = {"steps": more, "seconds": dt, "value": wl.units_per_step * more / dt, "ms_per_step": dt / more * 1e3}
+
+    # ---- single stream: one lane, kernels back to back (their stand-alone durations) ----------
+    single = None
+    if not args.no_single_stream and len(wl.contexts()) > 1 and not use_dist:
+        w1 = Workload(slam, torch, args, rank, local, 1, slots)
+        for _ in range(args.warmup):
+            step(w1)
+        fence(w1, collective=False)
+        e1, _, fam1, _ = timed(w1, args.steps, collective=False)
+        single = {"lanes": 1, "ms_per_step": e1 / args.steps * 1e3, "value": w1.units_per_step * args.steps / e1,
+                  "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam1.items() if v[1] > 0}}
+        del w1
+    elif len(wl.contexts()) == 1:
+        single = {"lanes": 1, "ms_per_step": elapsed_local / args.steps * 1e3, "value": wl.units_per_step * args.steps / elapsed_local,
+                  "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam.items() if v[1] > 0}, "note": "the main measurement is single-stream"}
+
     # ---- roofline of the dominant kernel (largest share of the HIP-event time) -----------
     ms = {k: v[0] for k, v in fam.items() if v[1] > 0}
     dom = max(ms, key=ms.get)
     dom_ms, dom_n = fam[dom]
-    avg_s = dom_ms / dom_n * 1e-3
-    psz = {"f64": 8, "f32": 4, "f16": 2}[args.points]
-    # SURVEY 8(d) prices a pair at (n_src+n_tar)*2*s + 72 B for point buffers of s bytes per coordinate.
-    # Since polar->Cartesian is fused into k_icp the kernel reads the raw float32 ranges instead
-    # (4 B per point) and no point buffer exists: (n_src+n_tar)*4 + 72 B per pair.
-    icp_bytes = scans_per_step * ((2 * args.beams) * 4 + 72)
-    grid_bytes = 9 * visits                                               # 9 B per in-bounds cell visit
-    alg_bytes = {"icp": icp_bytes, "grid": grid_bytes,
-                 "compose": scans_per_step * (72 + 24),
-                 "finalize": args.grid * args.grid * 9}.get(dom, 0)
-    kname = {"icp": "k_icp", "grid": "k_grid_update_replay", "compose": "k_pose_compose",
-             "finalize": "k_grid_finalize"}.get(dom, dom)
-    if dom == "grid" and args.grid_mode in (1, 3):
-        kname = "k_grid_update_win"
-    traffic, tsrc, valu_busy = load_traffic(kname)
-    achieved = alg_bytes / avg_s / 1e9
-    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                "valu_busy_frac_pmc": valu_busy,   # SQ_ACTIVE_INST_VALU share of the kernel's SIMD cycles (profiles/)
-                "avg_launch_ms": dom_ms / dom_n, "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms_per_step": {k: fam[k][0] / fam[k][1] for k in ms},
-                "timed": "start/stop HIP events carried by every dispatch of %d of %d lanes; a duration includes the time the kernel shares the chip with the other lanes' kernels"
-                         % (len(timed_lanes), len(lanes))}
-    # ICP is VALU-bound, not HBM-bound.  The figure below counts the distance
-    # evaluations an EXHAUSTIVE nearest-neighbour scan would make (iters * n_src * n_tar, what the
-    # reference does); the pruned search returns the same result evaluating about a fifth of them.
-    evals = float(iters.astype(np.int64).sum()) * args.beams * args.beams
-    icp_s = fam["icp"][0] / max(fam["icp"][1], 1) * 1e-3
-    roofline["icp_work"] = {"exhaustive_equivalent_distance_evals_per_s": evals / icp_s, "mean_iters": float(iters.mean()),
-                            "note": "equivalent brute-force rate; f64 VALU peak is %.1f TFLOP/s (~%.1e evals/s at 6 flop each)"
-                                    % (F64_VALU_PEAK_TFLOPS, F64_VALU_PEAK_TFLOPS * 1e12 / 6)}
-    lds_insts = load_pmc("k_icp").get("lds_insts_per_launch")
-    if lds_insts:
-        # SURVEY.md 8d asks for the ICP's LDS rate next to its VALU rate: an upper bound from the
-        # PMC count of wave-level LDS instructions, pricing each as a 64-lane 16-byte read
-        roofline["icp_work"]["lds"] = {"wave_instructions_per_launch": lds_insts,
-                                       "upper_bound_GBps": lds_insts * 1024.0 / icp_s / 1e9,
-                                       "peak_GBps": 256 * 128 * 2.4,      # 256 CUs x 128 B/clk x 2.4 GHz
-                                       "note": "most are per-lane ds_read_b128 of target points; box reads are broadcasts"}
-    grid_s = fam["grid"][0] / max(fam["grid"][1], 1) * 1e-3
-    roofline["grid_atomics"] = {"cell_visits_per_step": visits, "visits_per_s": visits / grid_s if grid_s else None}
+    alg = wl.algorithmic_bytes()
+    kname = wl.family_kernels.get(dom, dom)
+    # the stand-alone duration of the dominant kernel where one exists: with several lanes a
+    # kernel's duration includes the time it shares the chip with the other lanes' kernels
+    avg_ms = dom_ms / dom_n
+    alone_ms = single["kernel_ms_per_launch"].get(dom, avg_ms) if single else avg_ms
+    pmc = load_pmc(args.config, kname)
+    hbm = {"achieved": alg.get(dom, 0) / (alone_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "algorithmic_bytes_per_launch": alg.get(dom, 0)}
+    hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
+    traffic = pmc.get("hbm_bytes_per_launch")
+    if dom == "icp":
+        # k_icp is bound by f64 VALU issue, not by HBM: the roofline is
+        # the chip's f64 instruction issue rate, achieved = wave-level VALU instructions per launch
+        # (rocprofv3 SQ_INSTS_VALU of this same command, profiles/) / the live launch duration
+        insts = pmc.get("valu_insts_per_launch")
+        ach = insts / (alone_ms * 1e-3) if insts else None
+        roofline = {"kernel": kname, "bound": "valu_f64_issue", "achieved": ach, "peak": F64_ISSUE_PEAK, "unit": "wave-instructions/s",
+                    "frac": ach / F64_ISSUE_PEAK if ach else pmc.get("valu_busy_frac"), "traffic": traffic,
+                    "valu_busy_frac_pmc": pmc.get("valu_busy_frac"), "hbm": hbm,
+                    "note": "achieved = SQ_INSTS_VALU per launch (profiles/, same command) / stand-alone launch duration measured live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per f64 wave instruction"}
+    else:
+        roofline = dict(hbm, kernel=kname, bound="hbm", traffic=traffic)
+    roofline.update({"traffic_source": pmc.get("source"), "avg_launch_ms": alone_ms, "avg_launch_ms_overlapped": avg_ms, "launches": dom_n,
+                     "kernel_ms_per_launch_overlapped": {k: fam[k][0] / fam[k][1] for k in ms},
+                     "timed": "start/stop HIP events carried by every dispatch of all %d lanes; avg_launch_ms is the one-lane (stand-alone) duration, "
+                              "the overlapped durations include the time a kernel shares the chip with the other lanes' kernels" % len(wl.contexts())})
+    iters = np.asarray(wl.iters)
+    if "icp" in fam and fam["icp"][1]:
+        # The figure below counts the distance evaluations an EXHAUSTIVE nearest-neighbour scan would
+        # make (iters * n_src * n_tar, what the reference does); the pruned search returns the same
+        # result evaluating a fraction of them.
+        evals = float(iters.astype(np.int64).sum()) * args.beams * args.beams
+        icp_s = (single["kernel_ms_per_launch"].get("icp") if single else None) or fam["icp"][0] / fam["icp"][1]
+        icp_s *= 1e-3
+        roofline["icp_work"] = {"exhaustive_equivalent_distance_evals_per_s": evals / icp_s, "mean_iters": float(iters.mean()),
+                                "note": "equivalent brute-force rate; f64 VALU peak is %.1f TFLOP/s (~%.1e evals/s at 6 flop each)"
+                                        % (F64_VALU_PEAK_TFLOPS, F64_VALU_PEAK_TFLOPS * 1e12 / 6)}
+        lds_insts = load_pmc(args.config, "k_icp").get("lds_insts_per_launch")
+        if lds_insts:
+            roofline["icp_work"]["lds"] = {"wave_instructions_per_launch": lds_insts, "upper_bound_GBps": lds_insts * 1024.0 / icp_s / 1e9,
+                                           "peak_GBps": 256 * 128 * 2.4,
+                                           "note": "most are per-lane ds_read_b128 of target points; box reads are broadcasts"}
+    if "grid" in fam and fam["grid"][1]:
+        grid_s = ((single["kernel_ms_per_launch"].get("grid") if single else None) or fam["grid"][0] / fam["grid"][1]) * 1e-3
+        roofline["grid_cast"] = {"cell_visits_per_step": wl.visits, "visits_per_s": wl.visits / grid_s,
+                                 "algorithmic_GBps": 9 * wl.visits / grid_s / 1e9, "frac_of_hbm_peak": 9 * wl.visits / grid_s / 1e9 / HBM_PEAK_GBS}
 
     out = {
-        "metric": "scans/sec (360-beam ICP + 0.05 m grid update)", "value": value, "unit": "scans/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "metric": "scans/sec (360-beam ICP + 0.05 m grid update)" if args.config != "dense" else "scans/sec (1080-beam ICP + 0.02 m grid update)",
+        "value": value, "unit": "scans/s",
+        "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
-        "closing_collectives_ms": (t0 + elapsed_local - marks["drained"]) * 1e3,   # all_gather + barrier after the last replay
+        "closing_collectives_ms": closing_ms,   # all_gather + barrier after the last replay
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d-scan replay (every %dth message of a 10 Hz stream), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid"
-                               % (args.scans, args.stride, args.beams, args.max_iter, args.tol, args.grid, args.grid, args.reso),
-                   "scans_per_step_per_gpu": scans_per_step, "point_buffers": args.points,
-                   "point_buffers_note": "storage type of the points the scan matcher sees (arithmetic is float64 either way); "
-                                         "configs[1] names fp32: --points f32 runs at the same speed (0.180 vs 0.178 ms per step), "
-                                         "f64 is the default because it is bit-for-bit the reference's own arithmetic",
-                   "trajectories_per_gpu": 1,
-                   "pipeline": args.pipeline, "lanes": args.lanes, "grid_mode": args.grid_mode, "grid_group": args.grid_group,
-                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if world > 1 else "")},
+        "config": {"workload": wl.workload_name(), "name": args.config,
+                   "units_per_step_per_gpu": wl.units_per_step, "point_buffers": args.points,
+                   "point_buffers_note": "storage type of the points the scan matcher sees (arithmetic is float64 either way)",
+                   "pipeline": args.pipeline, "lanes": len(wl.contexts()), "grid_mode": args.grid_mode, "grid_group": args.grid_group,
+                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
         "roofline": roofline,
     }
-    if args.check and rank == 0:
-        from oracle import c_oracle as co
-        s = round(1.0 / args.reso)
-        og = co.Grid(args.grid, args.grid, float(s), args.grid / (2.0 * s), args.grid / (2.0 * s))
-        if args.points == "f64":
-            op, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, max_iter=args.max_iter, tolerance=args.tol,
-                                        threads=os.cpu_count() or 1, mt_grid=True)
-        else:
-            # reduced point storage: scan matching sees the points rounded to that type, the map
-            # is cast from the float64 points (tests/test_gpu_parity.py::test_replay_reduced_storage_vs_oracle)
-            npdt = {"f32": np.float32, "f16": np.float16}[args.points]
-            pts64 = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges])
-            pts = pts64.astype(npdt).astype(np.float64)
-            oT, oit, _ = co.icp_batch(pts[:-1], pts[1:], args.max_iter, args.tol)
-            op, sta, ov = np.empty((len(oT), 3)), [0.0, 0.0, 0.0], 0
-            for k in range(len(oT)):
-                sta = co.compose_pose(sta, oT[k])
-                op[k] = sta
-                wx, wy = co.world_points(op[k], pts64[k + 1][0], pts64[k + 1][1])
-                og.update(wx, wy, op[k][0], op[k][1])
-            ov = og.visits
-        cnt = grid.read(0, want=("pass", "hit"))
-        out["parity"] = {"pose_max_abs_err": float(np.max(np.abs(poses[0] - op))), "iters_equal": bool(np.array_equal(iters[0], oit)),
-                         "pmap_cell_mismatches": int(np.sum(pmap.cpu().numpy() != og.pmap)),
-                         "counter_cell_mismatches": int(np.sum(cnt["pass"] != og.pass_cnt) + np.sum(cnt["hit"] != og.hit_cnt)),
-                         "visits_equal": bool(visits == ov)}
+    if single:
+        out["single_stream"] = single
+    if sustained:
+        out["sustained"] = sustained
+    if rank == 0 and not args.no_parity:
+        out["parity"] = wl.parity(dev_results)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rep, args, args.cpu_seconds)
+        out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -1,0 +1,201 @@
+"""GPU parity at the STATED sizes of BASELINE.json configs[2], [3] (per-GPU share) and [4],
+through the C ABI, against the C oracle (oracle/checks.py), plus the regression tests of
+round-1 review findings (host-pointer replay with the "pipeline" option, the LDS-window
+sizing that once overran).  Run on the MI355X box with ``-m gpu``."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import c_oracle as co
+from oracle import checks
+
+pytestmark = pytest.mark.gpu
+FTOL = 1e-9
+AMIN, AMAX = -3.14159, 3.14159
+
+
+@pytest.fixture(scope="module")
+def slam():
+    p = pkg()
+    p._abi.default_context()
+    return p
+
+
+def _device_replay(slam, rep, points, xw, yw, reso):
+    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype=points)
+    grid = dr.make_grid(1, xw, yw, reso)
+    dr.run()
+    poses, T, it = dr.results()
+    dev = {"poses": poses[0], "T": T[0], "iters": it[0], "visits": grid.visits()}
+    dev.update(grid.read(0, want=("pmap", "pass", "hit")))
+    return dr, grid, dev
+
+
+def _assert_replay_parity(par):
+    assert par["iters_equal"], par
+    assert par["pose_max_abs_err"] < FTOL and par["T_max_abs_err"] < FTOL, par
+    assert par["counter_cell_mismatches"] == 0 and par["pmap_cell_mismatches"] == 0 and par["visits_equal"], par
+
+
+# ------------------------------------------------------------------ configs[4] as stated
+def test_config4_dense_1080_f16_2000x2000_tiles(slam, syn):
+    """BASELINE configs[4] in its stated form, all at once: 1080 beams, fp16 point buffers,
+    2000x2000 @ 0.02 m map, room x2, the tiled ray cast (automatic on a map this large), 48
+    scans.  The oracle's scan matcher is fed the fp16-rounded points, its
+    map the float64 ones."""
+    rep = syn.make_replay(48, 1080, seed=3, room_scale=2.0, stride=5)
+    dr, grid, dev = _device_replay(slam, rep, "f16", 2000, 2000, 0.02)
+    par = checks.compare_replay(dev, rep.ranges, AMIN, AMAX, 2000, 2000, 0.02, points="f16")
+    _assert_replay_parity(par)
+    assert dev["visits"] > 47 * 1080 * 100          # the rays really are hundreds of cells long
+    # the fp16 storage does change the answer (otherwise this would prove nothing about it)
+    dr64 = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype="f64")
+    dr64.run()
+    assert np.max(np.abs(dr64.results()[1][0] - dev["T"])) > 1e-6
+    # window mode (3) and direct atomics (0) give the same map as the tiles
+    for mode in (3, 0):
+        dr.ctx.set_option("grid_mode", mode)
+        dr.run()
+        r = grid.read(0, want=("pass", "hit"))
+        assert np.array_equal(r["pass"], dev["pass"]) and np.array_equal(r["hit"], dev["hit"]), mode
+
+
+# ------------------------------------------------------------------ configs[3] per-GPU share
+def test_config3_share_5000_scan_replay(slam, syn):
+    """One rank's share of BASELINE configs[3]: a 5 000-scan trajectory (seed 10 = rank 0's),
+    360 beams, 400x400 @ 0.05 m.  4 999 transforms cross the 2 048-step chunk of the pose
+    composition kernel twice."""
+    rep = syn.make_replay(5000, 360, seed=10, stride=5)
+    _, grid, dev = _device_replay(slam, rep, "f64", 400, 400, 0.05)
+    par = checks.compare_replay(dev, rep.ranges, AMIN, AMAX, 400, 400, 0.05)
+    _assert_replay_parity(par)
+    assert par["scans"] == 4999
+    assert int(dev["pass"].sum(dtype=np.int64)) + int(dev["hit"].sum(dtype=np.int64)) == dev["visits"]
+
+
+# ------------------------------------------------------------------ configs[2] at 10 000 particles
+def test_config2_10000_particles(slam, syn):
+    """BASELINE configs[2] at its stated size: 10 000 prior hypotheses of one 360-beam scan
+    pair, one 400x400 @ 0.05 m map per particle (12.8 GB of counters: the last maps lie beyond
+    4 GB offsets), live pmap.  The oracle runs 32 sampled particles incl. the first and last;
+    size-independent properties cover the rest."""
+    import torch
+    P = 10000
+    rep = syn.make_replay(2, 360, seed=2, stride=5)
+    mats = slam.prior_matrices(syn.particle_priors(P, seed=2))
+    pose_prev = np.random.default_rng(4).normal(0, 0.5, size=(P, 3))
+    grid = slam.DeviceGrid.metric(P, 400, 400, 0.05)
+    grid.live_pmap()
+    poses, T, it = slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, mats, pose_prev, grid=grid)
+    rng = np.random.default_rng(7)
+    sample = sorted(set([0, 1, P // 2, P - 2, P - 1] + rng.integers(0, P, size=27).tolist()))
+    par = checks.compare_particles(poses, T, it, lambda p: grid.read(p, want=("pmap", "pass", "hit")), sample,
+                                   rep.ranges[0], rep.ranges[1], AMIN, AMAX, mats, pose_prev, 400, 400, 0.05)
+    assert par["iters_equal"] and par["pose_max_abs_err"] < FTOL and par["T_max_abs_err"] < FTOL, par
+    assert par["counter_cell_mismatches"] == 0 and par["pmap_cell_mismatches"] == 0, par
+    # all 10 000: ICP results against the batched oracle (OpenMP), every particle
+    tar = np.array(co.laser_to_points(rep.ranges[0], AMIN, AMAX))
+    src = np.array(co.laser_to_points(rep.ranges[1], AMIN, AMAX))
+    m = mats
+    srcs = np.stack([m[:, 0, 0, None] * src[0] + m[:, 0, 1, None] * src[1] + m[:, 0, 2, None],
+                     m[:, 1, 0, None] * src[0] + m[:, 1, 1, None] * src[1] + m[:, 1, 2, None]], axis=1)
+    oT, oit, _ = co.icp_batch(np.broadcast_to(tar, (P,) + tar.shape), srcs, 30, 0.001)
+    assert np.array_equal(it, oit) and np.max(np.abs(T - oT)) < FTOL
+    # all 10 000 maps: every ray ends in one hit (or leaves the map), visits == sum of counters,
+    # the live pmap equals the rule applied to the counters (on the device, 14 GB: no read-back)
+    ps, ht = grid.counters_torch()
+    total = int(ps.sum(dtype=torch.int64).item()) + int(ht.sum(dtype=torch.int64).item())
+    assert total == grid.visits()
+    hits_per_map = ht.reshape(P, -1).sum(dim=1)
+    assert int(hits_per_map.max().item()) <= 360 and int(hits_per_map.min().item()) >= 300
+    per = 400 * 400
+    chunk = 500
+    live_ptr = grid.live_pmap()
+    for g0 in range(0, P, chunk):
+        p_, h_ = ps[g0:g0 + chunk], ht[g0:g0 + chunk]
+        want = torch.where((p_ + h_) == 0, 50, torch.where((h_ >= 1) | (p_ >= 1001), 100, 0)).to(torch.int8)
+        live = _live_view(torch, live_ptr + g0 * per, (chunk, 400, 400), ps.device)
+        assert bool(torch.equal(live, want)), g0
+    grid.close()
+
+
+def _live_view(torch, ptr, shape, device):
+    class V:
+        pass
+    v = V()
+    v.__cuda_array_interface__ = {"shape": shape, "typestr": "|i1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device=device)
+
+
+# ------------------------------------------------------------------ review findings of round 1
+def test_replay_host_with_pipeline_option_and_grid(slam, syn):
+    """slam_replay (host pointers) on a context with pipeline=1 and a map: the copies back must
+    wait for the compose / map streams (they once raced: stale poses)."""
+    rep = syn.make_replay(300, 360, seed=23, stride=5)
+    ctx = slam.Context(0)
+    ctx.set_option("pipeline", 1)
+    og = checks.metric_grid(400, 400, 0.05)
+    oposes, oT, oit, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8)
+    for _ in range(3):
+        grid = slam.DeviceGrid.metric(1, 400, 400, 0.05, context=ctx)
+        poses, T, it = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, context=ctx)
+        assert np.array_equal(it, oit) and np.max(np.abs(poses - oposes)) < FTOL and np.max(np.abs(T - oT)) < FTOL
+        r = grid.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap)
+        grid.close()
+    ctx.set_option("pipeline", 0)
+    ctx.close()
+
+
+def _fan(cx, cy, x_lo, x_hi, y_lo, y_hi, scale, off_x, off_y):
+    """World-frame endpoints whose cells lie on the far edges of the cell box [x_lo..x_hi] x
+    [y_lo..y_hi] (plus the corners), seen from the cell (cx, cy)."""
+    cells = [(x_hi, y) for y in range(y_lo, y_hi + 1)] + [(x, y_hi) for x in range(x_lo, x_hi + 1)]
+    cells += [(x_lo, y_lo), (x_lo, y_hi), (x_hi, y_lo)]
+    ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells])
+    oy = np.array([(c[1] + 0.5) / scale - off_y for c in cells])
+    return ox, oy, (cx + 0.5) / scale - off_x, (cy + 0.5) / scale - off_y
+
+
+@pytest.mark.parametrize("W,H", [(193, 191), (400, 189), (193, 192), (192, 193), (300, 123)])
+@pytest.mark.parametrize("y_origin", [100, 101, 102, 103])
+@pytest.mark.parametrize("live", [False, True])
+def test_window_kernel_subwindow_sizes(slam, W, H, y_origin, live):
+    """Deterministic shapes for the LDS-window ray caster's sub-window (grid_mode 3): a bounding
+    box that does not fit the 36 864-cell window, wider than 192 cells and with an odd height
+    (193x191 once wrote 96 dwords past the window; 400x189 likewise), with and without the live
+    pmap (whose quad alignment shifts the window's first row).  Counters, pmap and the visit
+    count must equal the oracle's, and no internal-error status may be raised."""
+    xw, yw, scale, off_x, off_y = 440, 400, 20.0, 11.0, 10.0
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", 3)
+    ctx.set_option("grid_group", 1)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, context=ctx)
+    if live:
+        g.live_pmap()
+    x_lo, y_lo = 10, y_origin
+    ox, oy, cx, cy = _fan(x_lo, y_lo, x_lo, x_lo + W - 1, y_lo, y_lo + H - 1, scale, off_x, off_y)
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    for _ in range(2):                                          # twice: the second pass adds to non-zero counters
+        g.update_host(ox, oy, cx, cy)
+        og.update(ox, oy, cx, cy)
+    ctx.check_status()
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt), (W, H, y_origin, live)
+    assert np.array_equal(r["pmap"], og.pmap) and g.visits() == og.visits
+    bx = np.nonzero(r["pass"].sum(axis=1) + r["hit"].sum(axis=1))[0]
+    by = np.nonzero(r["pass"].sum(axis=0) + r["hit"].sum(axis=0))[0]
+    assert (bx[-1] - bx[0] + 1, by[-1] - by[0] + 1) == (W, H)   # the box really has the stated shape
+    g.close()
+    ctx.close()
+
+
+def test_dist_replay_sharded_world1_hip_runner(slam, syn):
+    """dist.replay_sharded with the HIP runner (the multi-GPU entry of configs[3]) on one
+    rank: same poses as the oracle, gathered result == local result."""
+    reps = [syn.make_replay(60, 360, seed=10 + i, stride=5) for i in range(3)]
+    finals, local, (lo, hi) = slam.dist.replay_sharded(lambda i: reps[i].ranges, 3, AMIN, AMAX)
+    assert (lo, hi) == (0, 3) and finals.shape == (3, 3) and local.shape == (3, 59, 3)
+    for i in range(3):
+        op, _, _, _ = co.replay(reps[i].ranges, AMIN, AMAX, None, threads=8)
+        assert np.max(np.abs(local[i] - op)) < FTOL and np.array_equal(finals[i], local[i, -1])

@@ -80,7 +80,7 @@ def test_icp_degenerate_inputs(slam):
     # identical clouds: identity after the first convergence check
     pts = np.random.default_rng(0).normal(0, 2, size=(2, 50))
     T = icp.process(ones(pts), ones(pts))
-    assert np.max(np.abs(T - np.eye(3))) < 1e-12 and icp.last_iters == 1 or icp.last_iters == 2
+    assert np.max(np.abs(T - np.eye(3))) < 1e-12 and icp.last_iters in (1, 2)
     # every source point matches the same target point: W = 0 exactly -> R = I (as numpy's svd of zeros)
     tar = np.array([[0.0, 100.0, 200.0], [0.0, 100.0, 200.0]])
     src = np.array([[0.1, -0.2, 0.3], [0.2, 0.1, -0.3]])
