@@ -115,7 +115,7 @@ __device__ __forceinline__ void finish_wave(const GridDev &g, uint32_t *pass, in
     for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
     if ((threadIdx.x & 63) == 0) {
         if (m) atomicAdd(&pass[(size_t)pcx * g.yw + pcy], (unsigned)__popcll(m));
-        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
+        if (tot) atomicAdd(visit_slot(g.visits), (unsigned long long)tot);
         if (anybad) atomicOr(g.status, anybad);
     }
 }
@@ -233,6 +233,46 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
 // around the first origin; cells of a ray outside the window fall back to direct global
 // atomics, so the result is exact for any window.
 // ---------------------------------------------------------------------------------
+// Between a workgroup's own global atomics and its plain loads of the same cells: every wave waits
+// for its atomics to be acknowledged, then the workgroup barrier.  The map belongs to this
+// workgroup for the whole launch and none of its lines has been loaded before (no stale L1 copy
+// can exist), so nothing has to be written back or invalidated: a device-wide __threadfence()
+// here made every owner write the XCD's whole L2 back.
+#ifndef SLAM_OWNER_FENCE
+#define SLAM_OWNER_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+// Diagnostic build (-DSLAM_STAMPS, never shipped): thread 0 of every window workgroup adds the
+// shader-clock cycles of each phase to 64-bit counters behind the context's status word
+// (status + 8 ints), read back by slam_debug_read.
+#ifdef SLAM_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_t0);           \
+            st_t0 = t_;                                                                                  \
+        }                                                                                                \
+    } while (0)
+#define STAMP_END(k)                                                                                     \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_first);        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k) + 1, 1ull);             \
+        }                                                                                                \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_END(k)
+#endif
+#ifndef SLAM_EXP
+#define SLAM_EXP 0      // diagnostic builds: 1 no pmap loads, 2 no pass stores, 3 no loads, 4 no loads and no pass stores (wrong maps!)
+#endif
+#ifndef SLAM_SWEEP_BATCH
+#define SLAM_SWEEP_BATCH 4
+#endif
 #ifndef SLAM_WIN_CELLS
 #define SLAM_WIN_CELLS 36864
 #endif
@@ -405,16 +445,75 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
     return nvis;
 }
 
+// Single-scan owner form: the rays' bounding box is cut into strips of rows (x ranges) that each fit
+// the window, and the scan is walked once per strip, counting only the strip's cells.  A ray whose
+// x range misses the strip is skipped; a walk cannot be entered midway (its state is a rounded
+// running sum), so a ray that reaches a later strip is walked again from its start.  The path's
+// last cell gets its hit in the strip it lies in: the global counter by a fire-and-forget atomic
+// and bit 15 of its window cell, so that the sweep knows where this scan's hits fell.
+template <class Src>
+__device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src &src, const ScanConst &sc, int l, int s0,
+                                                    int nrays, int *next_ray, const unsigned short *order, unsigned *win,
+                                                    int wx0, int wy0, int W, int H, int Hp2, uint32_t *__restrict__ hit)
+{
+    unsigned nvis = 0;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(next_ray, kWave);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= nrays) break;
+        if (base + lane >= nrays) continue;
+        const int i = order ? (int)order[base + lane] : base + lane;   // longest rays first when sorted
+        int pox, poy, b2 = 0;
+        Ray ry;
+        if (!src.ray(l, s0, i, sc, g, pox, poy, b2)) continue;
+        if (max(sc.pcx, pox) < wx0 || min(sc.pcx, pox) >= wx0 + W) continue;   // never enters this strip
+        if (!ray_setup(sc.pcx, sc.pcy, pox, poy, ry)) continue;
+        const int klast = ry.flag ? 0 : ry.dx;                       // walk step of the path's LAST cell
+        const int ax_x = ry.steep ? 0 : 1, ax_y = ry.steep ? 1 : 0;  // cell step per walk step ...
+        const int ay_x = ry.steep ? ry.ystep : 0, ay_y = ry.steep ? 0 : ry.ystep;   // ... and per y step
+        int lx = ry.steep ? ry.y0 : ry.x0, ly = ry.steep ? ry.x0 : ry.y0;
+        double error = 0.0;                                           // bresenham.py:34
+        for (int k = 0; k <= ry.dx; ++k) {                            // :45
+            const unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
+            if (wx < (unsigned)W && wy < (unsigned)H) {               // in this strip (every in-map cell of the ray is in some strip)
+                ++nvis;                                               // mapping.py:41
+                unsigned *cell = &win[wx * Hp2 + (wy >> 1)];
+                const unsigned sh = (wy & 1u) * 16u;
+                if (k != klast) atomicAdd(cell, 1u << sh);            // mapping.py:43
+                else { atomicOr(cell, 0x8000u << sh); atomicAdd(&hit[(size_t)lx * g.yw + ly], 1u); }   // :45
+            }
+            error += ry.derr;                                         // bresenham.py:51
+            const bool stepy = error >= 0.5;                          // :53
+            lx += ax_x + (stepy ? ay_x : 0);
+            ly += ax_y + (stepy ? ay_y : 0);
+            error = stepy ? error - 1.0 : error;                      // :55
+        }
+    }
+    return nvis;
+}
+
 __host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)group * sizeof(ScanConst) + 15) & ~(size_t)15; }
 __host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
-__host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap)
+__host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap, int win_cells)
 {
-    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)kWinCells * 2 + kLdsGuard;
+    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)win_cells * 2 + kLdsGuard;
+}
+// Window capacity (16-bit cells) of a launch: kWinCells, or, for small groups, whatever still lets two
+// workgroups share a CU's 160 KiB (a single 360-beam scan: 40 288 cells instead of 36 864 - the
+// bounding box of a scan of the 10 m x 8 m benchmark room, padded to 16-cell pieces, is 35-37 k cells)
+inline int win_cells_for(int group, int sort_cap)
+{
+    const long half = 80 * 1024;
+    long other = (long)win_lds_bytes(group, sort_cap, 0);
+    long cells = ((half - other) / 2) & ~15L;
+    return cells > kWinCells ? (int)cells : kWinCells;
 }
 
 template <class Src>
 __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got,
-                                                          int exclusive, int sort_cap)
+                                                          int exclusive, int sort_cap, int win_cells)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS is carved for this launch's group size (win_lds_bytes): a small group leaves room for a
@@ -424,8 +523,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     int *hist = box + 16;                                                                 // [kSortBins]
     unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [sort_cap]
     unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);                       // [W][Hp/2] dwords
-    char *guard = reinterpret_cast<char *>(win) + (size_t)kWinCells * 2;
+    char *guard = reinterpret_cast<char *>(win) + (size_t)win_cells * 2;
     lds_guard_fill(guard);
+    STAMP_DECL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
@@ -439,11 +539,13 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // plain vectorised read-modify-write of the touched rectangle that also re-thresholds pmap
     const bool fused = exclusive && g.pmap_live && (g.yw & 3) == 0 && (((size_t)gi * g.xw * g.yw) & 3) == 0;
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
-    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; }
+    unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
+    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; }
     const bool sorted = nrays <= sort_cap;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
     if (tid < kSortBins) hist[tid] = 0;
     __syncthreads();
+    STAMP(0);                                   // scan constants
 
     // pass 1: bounding box of everything the group's rays can touch
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
@@ -468,28 +570,41 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     if (tid == 0) {
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         int W = 0, H = 0, covers = 1;
+        int fastwin = 0, strip_w = 0;                                // strips of the single-scan owner form
         if (x0 <= x1 && y0 <= y1) {
+#ifndef SLAM_NO_FAST_SWEEP
+            // Fast owner sweep (see the end of the kernel): one scan, one hit occupies, and the window,
+            // widened to whole 64-byte pieces of the counter rows (16 cells), still holds every cell.
+            if (fused && cnt == 1 && nrays < 32768 && g.hit_levels == 1 && (g.yw & 15) == 0) {
+                const int ya = y0 & ~15, Ha = ((y1 | 15) + 1) - ya, Wb = x1 - x0 + 1;
+                int S = (int)(((long)Wb * Ha + win_cells - 1) / win_cells), Ws = (Wb + S - 1) / S;
+                while ((long)Ws * Ha > win_cells && S < Wb) { ++S; Ws = (Wb + S - 1) / S; }
+                if ((long)Ws * Ha <= win_cells) { y0 = ya; y1 = ya + Ha - 1; fastwin = S; strip_w = Ws; }
+            }
+#endif
             if (fused) y0 &= ~3;                                      // quads of the fused flush line up with the window's dwords
             W = x1 - x0 + 1; H = y1 - y0 + 1;
-            if ((long)W * ((H + 1) & ~1) > kWinCells) {               // keep a sub-rectangle around the first origin
-                int Hd = min(H, 192), Wd = min(W, kWinCells / ((Hd + 1) & ~1));   // rows are stored padded to an even height
+            if (!fastwin && (long)W * ((H + 1) & ~1) > win_cells) {   // keep a sub-rectangle around the first origin
+                int Hd = min(H, 192), Wd = min(W, win_cells / ((Hd + 1) & ~1));   // rows are stored padded to an even height
                 int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
                 if (fused) cy0 &= ~3;
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
                 covers = 0;
             }
-            // the window is W rows of (H + 1) / 2 dwords: it must fit the kWinCells 16-bit cells carved
+            // the window is W rows of (H + 1) / 2 dwords: it must fit the win_cells 16-bit cells carved
             // for it.  Should the sizing above ever be wrong again (it once used the unpadded height: a
             // 193 x 191 box wrote 96 dwords past the window), fall back to no window at all - every cell
             // then takes the direct-atomic path, still exact - and raise the internal-error status bit.
-            if ((long)W * ((H + 1) >> 1) > kWinCells / 2) {
+            if ((long)(fastwin ? strip_w : W) * ((H + 1) >> 1) > win_cells / 2) {
                 atomicOr(g.status, kStatusGuard);
+                fastwin = 0;
                 W = 0; H = 0; covers = 0;
             }
         }
-        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers;
+        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers; box[10] = fastwin; box[11] = strip_w;
     }
     __syncthreads();
+    STAMP(1);                                   // pass 1: endpoints, bounding box, histogram
     const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
     const bool covers = box[8] != 0;      // the window holds every in-map cell the group can touch
     const int Hp2 = (H + 1) >> 1;         // dwords per window row
@@ -508,15 +623,20 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         for (int r = tid; r < nrays; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
         __syncthreads();
     }
-    for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
-    __syncthreads();
-
-    // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
     unsigned nvis = 0;
     const unsigned short *ord = sorted ? order : nullptr;
-    if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
-    else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
-    __syncthreads();
+    const int strips = box[10], strip_w = box[11];
+    const bool fast = strips != 0;        // single-scan owner form (the sweep at the end of the kernel)
+    if (!fast) {
+        for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
+        __syncthreads();
+        STAMP(2);                                   // sort + zero
+        // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
+        if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
+        else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
+        __syncthreads();
+        STAMP(3);                                   // walk
+    }
 
     // flush: one wave per window row, lanes along y (contiguous in the [x][y] map), two cells per lane
     // every workgroup flushes the same part of the map: start each one at a different row so
@@ -532,21 +652,101 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             if (p1) atomicAdd(&pass[gbase + 2 * d + 1], p1);          // p1 != 0 implies 2d+1 < H
         }
     }
-    unsigned tot = wave_sum_u32(nvis);
-    int anybad = bad;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
-    if (lane == 0) {
-        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
-        if (anybad) atomicOr(g.status, anybad);
-    }
     // Live pmap: this workgroup is the only writer of its map during the launch, so once its own
     // atomics (hits, out-of-window passes) have landed it finishes every cell its rays could have
     // touched - the bounding box of pass 1, clamped to the map - in one sweep: add the window's
     // pass counts with plain 16-byte read-modify-writes (no flush atomics) and re-threshold pmap,
     // the finalize pass restricted to what changed.
-    if (exclusive && g.pmap_live) {
-        __threadfence();
+    if (fast) {
+        // Single-scan owner form.  Nothing of this map is read that an atomic of this launch wrote:
+        // pass counts come from the window, "a hit fell here" from the window's flag bits (the hit
+        // COUNTERS are bumped by the fire-and-forget atomics of the walk and never read), and the
+        // cell's earlier state from the live pmap itself: with one hit occupying, pmap == 100 says
+        // "hit before or pass >= threshold" and counters only grow, so an occupied cell stays
+        // occupied; otherwise hit == 0 and the new pass count decides (mapping.py:47-50).
+        // The window's rows are whole 64-byte pieces of the counter rows (16 cells = 4 quads = 4
+        // lanes): a piece the scan touched is read and written back whole, an untouched piece is
+        // neither read nor written; pmap is stored only where it changes.  No cell is ever updated
+        // by a global atomic: a bounding box larger than the window is cut into strips of rows, each
+        // walked and swept in turn (a rotated 10 m x 8 m room spans ~250 x 250 cells: two strips).
+        const uint32_t pthr = g.pass_thresh[0];
+        int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
+        const int qrow = H >> 2;                                      // H is a multiple of 16 here
+        const unsigned qinv = (unsigned)((0x100000000ull + (unsigned)qrow - 1) / (unsigned)qrow);   // q / qrow == umulhi(q, qinv), q < 2^16
+        constexpr int kBatch = SLAM_SWEEP_BATCH;
+        for (int strip = 0; strip < strips; ++strip) {
+        const int sx0 = wx0 + strip * strip_w, SW = min(strip_w, wx0 + W - sx0), total = SW * qrow;
+        if (strip) __syncthreads();                                   // the previous strip's sweep has read the window
+        for (int w = tid; w < SW * Hp2; w += blockDim.x) win[w] = 0u;
+        if (tid == 0) box[9] = 0;
+        __syncthreads();
+        STAMP(2);                                   // (sort +) zero
+        nvis += cast_rays_strip(g, src, sc[0], l, s0, nrays, &box[9], ord, win, sx0, wy0, SW, H, Hp2, hit);
+        __syncthreads();
+        STAMP(3);                                   // walk
+        for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
+            uint4 p[kBatch];
+            uint32_t om[kBatch], d0[kBatch], d1[kBatch];
+            size_t at[kBatch];
+            bool live[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int q = q0 + u * (int)blockDim.x;
+                d0[u] = d1[u] = 0u;
+                if (q < total) {
+                    const int r = (int)__umulhi((unsigned)q, qinv), c = q - r * qrow;
+                    const uint2 d = *reinterpret_cast<const uint2 *>(win + (r * Hp2 + 2 * c));
+                    d0[u] = d.x; d1[u] = d.y;
+                    at[u] = (size_t)(sx0 + r) * g.yw + (wy0 + 4 * c);
+                }
+                // the four lanes of a 64-byte piece decide together (total and blockDim are multiples of 4)
+                const unsigned long long m = __ballot((d0[u] | d1[u]) != 0u);
+                live[u] = ((m >> (lane & 60)) & 0xFull) != 0ull;
+                if (live[u]) {
+#if SLAM_EXP == 3 || SLAM_EXP == 4
+                    p[u] = make_uint4(0, 0, 0, 0);
+#else
+                    p[u] = *reinterpret_cast<const uint4 *>(pass + at[u]);
+#endif
+#if SLAM_EXP == 1 || SLAM_EXP == 3 || SLAM_EXP == 4
+                    om[u] = 0;
+#else
+                    om[u] = *reinterpret_cast<const uint32_t *>(pm + at[u]);
+#endif
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (!live[u]) continue;
+                const uint32_t c0 = d0[u] & 0x7fffu, c1 = (d0[u] >> 16) & 0x7fffu, c2 = d1[u] & 0x7fffu, c3 = (d1[u] >> 16) & 0x7fffu;
+                p[u].x += c0; p[u].y += c1; p[u].z += c2; p[u].w += c3;
+#if SLAM_EXP != 2 && SLAM_EXP != 4
+                *reinterpret_cast<uint4 *>(pass + at[u]) = p[u];
+#endif
+                if (!(d0[u] | d1[u])) continue;
+                const uint32_t o = om[u];
+                // per byte: 1 where the cell is occupied afterwards - it was (bit 6 is set in 100 only, not
+                // in 0 or 50), a hit fell on it, or its pass count reached the threshold
+                uint32_t occ = (o >> 6) & 0x01010101u;
+                occ |= ((d0[u] >> 15) & 1u) | ((d0[u] >> 31) << 8) | (((d1[u] >> 15) & 1u) << 16) | ((d1[u] >> 31) << 24);
+                occ |= (p[u].x >= pthr ? 1u : 0u) | (p[u].y >= pthr ? 0x100u : 0u) | (p[u].z >= pthr ? 0x10000u : 0u) | (p[u].w >= pthr ? 0x1000000u : 0u);
+                // per byte: 0xff where this scan touched the cell (passed through or hit)
+                const uint32_t tm = ((d0[u] & 0xffffu) ? 0xffu : 0u) | ((d0[u] >> 16) ? 0xff00u : 0u) | ((d1[u] & 0xffffu) ? 0xff0000u : 0u) |
+                                    ((d1[u] >> 16) ? 0xff000000u : 0u);
+                const uint32_t out = (o & ~tm) | ((occ * 100u) & tm);
+                if (out != o) *reinterpret_cast<uint32_t *>(pm + at[u]) = out;
+            }
+        }
+#ifdef SLAM_STAMPS
+        __syncthreads();
+#endif
+        STAMP(4);                                   // sweep
+        }   // strips
+#ifdef SLAM_STAMPS
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + 7, (unsigned long long)strips);
+#endif
+    } else if (exclusive && g.pmap_live) {
+        SLAM_OWNER_FENCE();
         __syncthreads();
         const int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         if (x0 <= x1 && y0 <= y1) {
@@ -600,6 +800,18 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
         }
     }
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if (lane == 0) {
+        if (tot) atomicAdd(wg_visits, (unsigned long long)tot);      // summed per workgroup in LDS: ONE global add, at the very end
+        if (anybad) atomicOr(g.status, anybad);
+    }
+    __syncthreads();
+    if (tid == 0 && *wg_visits) atomicAdd(visit_slot(g.visits), *wg_visits);
+    STAMP(4);                                   // flush / sweep
+    STAMP_END(5);                               // [5] lifetime, [6] workgroups
     lds_guard_check(guard, g.status);
 }
 
@@ -607,7 +819,7 @@ template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
 {
-    const size_t lds_max = win_lds_bytes(kWinMaxGroup, kMaxSortRays);
+    const size_t lds_max = win_lds_bytes(kWinMaxGroup, kMaxSortRays, kWinCells);
     static bool attr_done[2] = {false, false};
     constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
     if (!attr_done[which]) {
@@ -628,10 +840,14 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     // exclusive sweep (a streaming pass over the touched rectangle) need lanes for memory
     // operations in flight even when there are few rays (measured on 10 000 single-scan groups:
     // 2.88 ms with 128 threads, 2.05 ms with 512)
-    if (threads < 512) threads = 512;
+#ifndef SLAM_WIN_MIN_THREADS
+#define SLAM_WIN_MIN_THREADS 512
+#endif
+    if (threads < SLAM_WIN_MIN_THREADS) threads = SLAM_WIN_MIN_THREADS;
     const int sort_cap = win_sort_cap((long)group * n);
-    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap), s, g, src, group, got,
-                exclusive, sort_cap);
+    const int win_cells = win_cells_for(group, sort_cap);
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
+                exclusive, sort_cap, win_cells);
     return hipGetLastError();
 }
 
@@ -795,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratc
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
     if ((threadIdx.x & 63) == 0) {
-        if (tot) atomicAdd(g.visits, (unsigned long long)tot);
+        if (tot) atomicAdd(visit_slot(g.visits), (unsigned long long)tot);
         if (anybad) atomicOr(g.status, anybad);
     }
 }

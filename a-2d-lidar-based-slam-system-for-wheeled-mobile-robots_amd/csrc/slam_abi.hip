@@ -467,6 +467,18 @@ int slam_timing_read(slam_ctx *c, double ms_out[SLAM_K_COUNT], int64_t launches_
     return SLAM_OK;
 }
 
+#ifdef SLAM_STAMPS
+/* diagnostic builds only: the 256-byte status block (word 0: status bits; from word 8: phase counters) */
+int slam_debug_read(slam_ctx *c, void *out256, int clear)
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out256, c->status, 256, hipMemcpyDeviceToHost));
+    if (clear) HIPCHK(hipMemset(reinterpret_cast<char *>(c->status) + 32, 0, 224));
+    return SLAM_OK;
+}
+#endif
+
 /* ---- ICP ------------------------------------------------------------------------ */
 
 int slam_scan_to_points_dev(slam_ctx *c, const float *ranges, const double *cos_t, const double *sin_t, int B, int n,
@@ -679,7 +691,7 @@ int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double of
     for (uint32_t k = 0; k < (uint32_t)kMaxHitLevels; ++k) g->d.pass_thresh[k] = k < levels ? table[k] : 0;
     g->d.status = c->status;
     // one allocation [pass | hit | visit counter] so that a reset is a single memset
-    g->state_bytes = align_up(cells * 4) * 2 + 256;
+    g->state_bytes = align_up(cells * 4) * 2 + align_up((size_t)kVisitSlots * kVisitStride * sizeof(unsigned long long));
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d.pass), g->state_bytes);
     if (e == hipSuccess) {
         g->d.hit = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(g->d.pass) + align_up(cells * 4));
@@ -944,9 +956,11 @@ int slam_grid_visits(slam_ctx *c, slam_grid *g, uint64_t *visits_out)
     TRY(use(c));
     TRY(grid_on_main(c));
     REQUIRE(g && visits_out, "null pointer");
-    unsigned long long v = 0;
-    D2H(&v, g->visits, sizeof v);
+    static thread_local unsigned long long slots[kVisitSlots * kVisitStride];
+    D2H(slots, g->visits, sizeof slots);
     HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    for (int k = 0; k < kVisitSlots; ++k) v += slots[(size_t)k * kVisitStride];
     *visits_out = v;
     return SLAM_OK;
 }

@@ -95,12 +95,23 @@ hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int 
 
 // ---- grid --------------------------------------------------------------------------
 constexpr int kMaxHitLevels = 8;
+constexpr int kVisitSlots = 256;         // power of two
+constexpr int kVisitStride = 8;          // unsigned long longs between slots (64 bytes)
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long *visit_slot(unsigned long long *visits)
+{
+    return visits + (size_t)((blockIdx.x + blockIdx.y * 131u) & (unsigned)(kVisitSlots - 1)) * kVisitStride;
+}
+#endif
 
 struct GridDev {
     int G, xw, yw;
     double scale, off_x, off_y;
     uint32_t *pass, *hit;          // [G][xw][yw]
-    unsigned long long *visits;    // in-bounds cell visits since reset
+    // In-bounds cell visits since reset: kVisitSlots counters, one per 64-byte line; a workgroup adds
+    // to the slot of its block index and slam_grid_visits sums them.  (One shared counter made every
+    // wave of a 10 000-workgroup launch queue on one address: 80 000 serialised atomics, 1.6 ms.)
+    unsigned long long *visits;
     int *status;                   // sticky kStatus* bits (context-wide)
     // Occupied rule on the integer counters (see slam_grid_create): a cell with h hits and p
     // passes is occupied iff h >= hit_levels or p >= pass_thresh[h].

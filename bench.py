@@ -304,7 +304,9 @@ class ParticleWorkload:
         ct, st = A.trig_tables(AMIN, AMAX, n)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         self.mats = slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2 + rank))
-        self.pose_prev = np.random.default_rng(4 + rank).normal(0, 0.5, size=(P, 3))
+        # the hypotheses differ by their prior perturbation only; every particle
+        # starts the step at the same pose (tests/test_gpu_configs.py also runs scattered poses)
+        self.pose_prev = np.zeros((P, 3))
         self.t = dict(ranges2=d(self.rep.ranges.astype(np.float32)), cos_t=d(ct), sin_t=d(st), prior=d(self.mats.reshape(P, 6)),
                       pose_prev=d(self.pose_prev), poses=torch.empty((P, 3), dtype=torch.float64, device=self.dev),
                       T=torch.empty((P, 9), dtype=torch.float64, device=self.dev),
@@ -388,7 +390,19 @@ def main():
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout
+        # for the ONE JSON line (the banner goes to stderr instead)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     slam = importlib.import_module(PKG)

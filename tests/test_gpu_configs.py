@@ -157,14 +157,15 @@ def _fan(cx, cy, x_lo, x_hi, y_lo, y_hi, scale, off_x, off_y):
     return ox, oy, (cx + 0.5) / scale - off_x, (cy + 0.5) / scale - off_y
 
 
-@pytest.mark.parametrize("W,H", [(193, 191), (400, 189), (193, 192), (192, 193), (300, 123)])
+@pytest.mark.parametrize("W,H", [(193, 191), (400, 189), (193, 192), (192, 193), (300, 123), (150, 101), (37, 203), (5, 3)])
 @pytest.mark.parametrize("y_origin", [100, 101, 102, 103])
 @pytest.mark.parametrize("live", [False, True])
 def test_window_kernel_subwindow_sizes(slam, W, H, y_origin, live):
     """Deterministic shapes for the LDS-window ray caster's sub-window (grid_mode 3): a bounding
     box that does not fit the 36 864-cell window, wider than 192 cells and with an odd height
     (193x191 once wrote 96 dwords past the window; 400x189 likewise), with and without the live
-    pmap (whose quad alignment shifts the window's first row).  Counters, pmap and the visit
+    pmap (whose quad alignment shifts the window's first row); the last three shapes fit the
+    window (with the live pmap: the owner's fast sweep, odd widths and heights).  Counters, pmap and the visit
     count must equal the oracle's, and no internal-error status may be raised."""
     xw, yw, scale, off_x, off_y = 440, 400, 20.0, 11.0, 10.0
     ctx = slam.Context(0)
@@ -199,3 +200,33 @@ def test_dist_replay_sharded_world1_hip_runner(slam, syn):
     for i in range(3):
         op, _, _, _ = co.replay(reps[i].ranges, AMIN, AMAX, None, threads=8)
         assert np.max(np.abs(local[i] - op)) < FTOL and np.array_equal(finals[i], local[i, -1])
+
+
+def test_single_scan_owner_sweep_pass_threshold(slam):
+    """The fast owner sweep of a single scan decides pmap from the live pmap's previous value and
+    the new pass count: 300 rays along one line per scan, so the line's cells cross the 1001-pass
+    threshold during the 4th scan; a cell hit once stays occupied when later only passed through."""
+    ctx = slam.Context(0)
+    g = slam.DeviceGrid(1, 200, 200, 10.0, 10.0, 10.0, context=ctx)
+    g.live_pmap()
+    og = co.Grid(200, 200)
+    ox, oy = np.full(300, 3.05), np.full(300, 1.55)
+    for k in range(5):
+        g.update_host(ox, oy, 0.0, 0.0)
+        og.update(ox, oy, 0.0, 0.0)
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt), k
+        assert np.array_equal(r["pmap"], og.pmap), k
+        assert (r["pmap"][110, 105] == 100) == (k >= 3)              # a pass-through cell of the line
+    # a shorter ray now ends (hits) in a cell that so far was only passed through, then longer rays
+    # pass through that cell again: it stays occupied
+    for ex, ey in ((-2.05, 0.0), (-3.05, 0.0), (-3.05, 0.0)):
+        g.update_host(np.array([ex]), np.array([ey]), 0.0, 0.0)
+        og.update(np.array([ex]), np.array([ey]), 0.0, 0.0)
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap)
+        assert r["pmap"][79, 100] == 100 and r["pmap"][85, 100] == 0
+    assert r["hit"][79, 100] == 1 and r["pass"][79, 100] == 2 and r["hit"][69, 100] == 2
+    ctx.check_status()
+    g.close()
+    ctx.close()

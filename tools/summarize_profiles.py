@@ -10,7 +10,10 @@
                                    their bytes, MI355X_MICROARCH.md HBM section) and the VALU
                                    busy share, read by bench.py for roofline.traffic
 
-usage: summarize_profiles.py <gpurun_out/prof_tag> <tag>"""
+usage: summarize_profiles.py <gpurun_out/prof_tag_config> <tag> [config]
+
+pmc_traffic.json is keyed by bench.py --config ({"replay": {kernel: ...}, "particles": ...});
+the entry of the given config is replaced, the others are kept."""
 import collections
 import csv
 import glob
@@ -29,6 +32,8 @@ def short(name):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "replay"
+    tag = tag if cfg == "replay" else "%s_%s" % (tag, cfg)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(src, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -42,7 +47,7 @@ def main():
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    lines = ["# rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --lanes 1",
+    lines = ["# rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --config %s --no-cpu-baseline --lanes 1 (few steps)" % cfg,
              "# per-launch averages; FETCH_SIZE / WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes)", ""]
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
@@ -81,7 +86,15 @@ def main():
                       "lds_insts_per_launch": avg("SQ_INSTS_LDS")}
         lines.append("%s HBM %.3f MB VALU busy %s" % (k, hbm / 1e6, "n/a" if busy is None else "%.1f %%" % (100 * busy)))
     open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
-    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    allcfg = {}
+    try:
+        allcfg = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+        if "k_icp" in allcfg:                     # round-1 layout (replay only, flat)
+            allcfg = {"replay": allcfg}
+    except Exception:
+        allcfg = {}
+    allcfg[cfg] = traffic
+    json.dump(allcfg, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     if os.path.isdir(os.path.join(root, "profiles")) and os.access(os.path.join(root, "profiles"), os.W_OK):
         for f in os.listdir(dst):
             shutil.copy(os.path.join(dst, f), os.path.join(root, "profiles", f))
