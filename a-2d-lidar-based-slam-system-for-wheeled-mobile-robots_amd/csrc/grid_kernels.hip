@@ -505,7 +505,7 @@ __host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap, int win
 // bounding box of a scan of the 10 m x 8 m benchmark room, padded to 16-cell pieces, is 35-37 k cells)
 inline int win_cells_for(int group, int sort_cap)
 {
-    const long half = 80 * 1024;
+    const long half = 80 * 1024 - 512;                               // (a little room for allocation granules)
     long other = (long)win_lds_bytes(group, sort_cap, 0);
     long cells = ((half - other) / 2) & ~15L;
     return cells > kWinCells ? (int)cells : kWinCells;
@@ -815,6 +815,316 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     lds_guard_check(guard, g.status);
 }
 
+
+// ---------------------------------------------------------------------------------
+// Single-scan owner kernel (DESIGN.md "K4 owner"): ONE scan cast into a map that this workgroup
+// owns for the whole launch - the per-particle maps of BASELINE.json configs[2], and
+// Mapping.update of one scan - with the live pmap kept current.  No cell is updated by a global
+// atomic and nothing an atomic wrote is read back:
+//   * every ray's walk state lives in registers (up to kOwnerRays rays per lane, longest rays in
+//     the lowest waves), so a bounding box larger than the LDS window is handled by cutting it
+//     into strips of rows (x ranges) that are walked and swept in turn, in ascending x.  The
+//     reference walks along +x (or +y for steep lines) after its endpoint swaps, so the map x of
+//     a walk never decreases except for steep lines that step towards -x: every other ray resumes
+//     in a strip where it left the previous one and is walked exactly ONCE; those (a quarter of
+//     the rays, and only when there is more than one strip) restart from their first cell in
+//     every strip, because a walk cannot be entered midway - its state is a rounded running sum
+//     (bresenham.py:45-55: the same operations in the same order either way);
+//   * the path's last cell is the endpoint cell itself (the path runs start -> end inclusive):
+//     it takes the hit without being walked to - a fire-and-forget atomic on the hit counter,
+//     which is never read, and bit 15 of its 16-bit window cell;
+//   * the sweep of a strip reads the window, adds the pass counts into whole 64-byte pieces of the
+//     counter rows (plain 16-byte loads / stores of touched pieces only) and re-thresholds pmap
+//     from the window's flag bits, the new pass counts and the live pmap's previous value: with
+//     one hit occupying (the reference's +20 > 10), pmap == 100 says "hit before or pass >=
+//     threshold" and counters only grow, so an occupied cell stays occupied; otherwise hit == 0
+//     and the new pass count decides (mapping.py:42-50).
+// Rays that leave the map (mapping.py:41 drops their outside cells) are rare and take a plain
+// bounds-checked walk per strip.
+// ---------------------------------------------------------------------------------
+#ifndef SLAM_OWNER_THREADS
+#define SLAM_OWNER_THREADS 512
+#endif
+constexpr int kOwnerThreads = SLAM_OWNER_THREADS;   // 8 waves: two workgroups per CU at up to 128 VGPRs
+constexpr int kOwnerMaxRays = 2;                    // rays per lane (template parameter: 1 up to 512 beams)
+
+struct OwnRay {
+    int lx, h;            // current cell: map x, halfword index in the strip's window
+    int k, kend, klast;   // next walk step, last walk step, walk step of the path's last cell (takes the hit instead)
+    int dlx_k, dlx_y;     // map-x step per walk step / per y advance
+    int dh_k, dh_y;       // window halfword step per walk step / per y advance
+    int ly;               // map y of the current cell (kept current between strips only)
+    double error, derr;
+    __device__ __forceinline__ void start(const Ray &rr, int H)
+    {
+        k = 0; kend = rr.dx; klast = rr.flag ? 0 : rr.dx;
+        lx = rr.steep ? rr.y0 : rr.x0;
+        ly = rr.steep ? rr.x0 : rr.y0;
+        dlx_k = rr.steep ? 0 : 1; dlx_y = rr.steep ? rr.ystep : 0;
+        dh_k = rr.steep ? 1 : H;  dh_y = rr.steep ? rr.ystep * H : rr.ystep;
+        error = 0.0; derr = rr.derr;                                  // bresenham.py:34-35
+        h = 0;
+    }
+};
+
+template <class Src, int kOwnerRays>
+__global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, Src src, int sort_cap, int win_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ScanConst *sc = reinterpret_cast<ScanConst *>(smem);
+    int *box = reinterpret_cast<int *>(smem + win_sc_bytes(1));
+    int *hist = box + 16;
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);
+    unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);
+    char *guard = reinterpret_cast<char *>(win) + (size_t)win_cells * 2;
+    lds_guard_fill(guard);
+    STAMP_DECL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.y, gi = src.own_grid(l), n = src.n;
+    uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
+    int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
+    unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
+    unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is first zeroed
+
+    if (tid == 0) {
+        src.scan_const(l, 0, g, sc[0]);
+        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; *wg_visits = 0ull; box[14] = 0;
+    }
+    if (tid < kSortBins) hist[tid] = 0;
+    __syncthreads();
+    STAMP(0);
+    const ScanConst c0 = sc[0];
+
+    // pass 1: endpoints, bounding box, length histogram
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
+    for (int r = tid; r < n; r += blockDim.x) {
+        int pox, poy, len = 0;
+        if (src.ray(l, 0, r, c0, g, pox, poy, bad)) {
+            bx0 = min(bx0, min(pox, c0.pcx)); bx1 = max(bx1, max(pox, c0.pcx));
+            by0 = min(by0, min(poy, c0.pcy)); by1 = max(by1, max(poy, c0.pcy));
+            len = max(abs(pox - c0.pcx), abs(poy - c0.pcy));
+        }
+        int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);      // longest first
+        bins[r] = (unsigned short)bin;
+        atomicAdd(&hist[bin], 1);
+    }
+    bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
+    if (lane == 0 && bx0 <= bx1) {
+        atomicMin(&box[0], bx0); atomicMin(&box[1], by0); atomicMax(&box[2], bx1); atomicMax(&box[3], by1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // window = bounding box clamped to the map, rows widened to whole 16-cell pieces, cut into
+        // S strips of at most Ws rows that each fit the window
+        int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
+        int S = 0, Ws = 0, ya = 0, Ha = 0;
+        if (x0 <= x1 && y0 <= y1) {
+            ya = y0 & ~15; Ha = ((y1 | 15) + 1) - ya;
+            const int Wb = x1 - x0 + 1;
+            S = (int)(((long)Wb * Ha + win_cells - 1) / win_cells); Ws = (Wb + S - 1) / S;
+            while ((long)Ws * Ha > win_cells) { ++S; Ws = (Wb + S - 1) / S; }   // (the host made sure one row fits: yw <= win_cells)
+        }
+        box[4] = x0; box[5] = ya; box[6] = x1 - x0 + 1; box[7] = Ha; box[10] = S; box[11] = Ws;
+    }
+    if (wave == 0) {                                                 // counting sort by length bin: scan of the histogram
+        int a = hist[2 * lane], b2 = hist[2 * lane + 1], tot = a + b2, inc = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
+        hist[2 * lane] = inc - tot;
+        hist[2 * lane + 1] = inc - tot + a;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
+    __syncthreads();
+    STAMP(1);
+    const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7], strips = box[10], strip_w = box[11];
+    const int Hp2 = H >> 1;
+
+    // this lane's rays: sorted rays tid, tid + blockDim, ...
+    OwnRay ry[kOwnerRays];
+    int pox[kOwnerRays], poy[kOwnerRays];
+    // 0: nothing to walk; 1: all cells in the map, map x never decreases along the walk; 2: all cells in
+    // the map, map x decreases (steep, towards -x): restarted in every strip; 3: leaves the map
+    unsigned kind[kOwnerRays];
+    unsigned nvis = 0;
+    int unsafe = 0;
+#pragma unroll
+    for (int j = 0; j < kOwnerRays; ++j) {
+        kind[j] = 0u; pox[j] = poy[j] = 0;
+        Ray rr;
+        rr.x0 = rr.y0 = 0; rr.dx = -1; rr.ystep = 1; rr.derr = 0.0; rr.steep = rr.flag = false;
+        ry[j].start(rr, H);                                          // kend = -1: never active
+        const int sr = tid + j * (int)blockDim.x;
+        if (sr >= n || strips == 0) continue;
+        int b2 = 0;
+        if (!src.ray(l, 0, (int)order[sr], c0, g, pox[j], poy[j], b2)) continue;
+        if (!ray_setup(c0.pcx, c0.pcy, pox[j], poy[j], rr)) continue;          // identical cells: empty path (bresenham.py:10-11)
+        const bool inmap = (unsigned)c0.pcx < (unsigned)g.xw && (unsigned)c0.pcy < (unsigned)g.yw &&
+                           (unsigned)pox[j] < (unsigned)g.xw && (unsigned)poy[j] < (unsigned)g.yw;
+        if (!inmap) { kind[j] = 3u; unsafe = 1; continue; }
+        kind[j] = (rr.steep && rr.ystep < 0 && strips > 1) ? 2u : 1u;
+        nvis += (unsigned)rr.dx + 1u;                                // every cell of the path is in the map (mapping.py:41)
+        ry[j].start(rr, H);
+    }
+    if (unsafe) box[14] = 1;
+    __syncthreads();
+    const bool any_unsafe = box[14] != 0;
+
+    const uint32_t pthr = g.pass_thresh[0];
+    const int qrow = H >> 2;                                         // quads per window row (H is a multiple of 16)
+    const unsigned qinv = qrow ? (unsigned)((0x100000000ull + (unsigned)qrow - 1) / (unsigned)qrow) : 0u;   // q / qrow == umulhi(q, qinv)
+    for (int strip = 0; strip < strips; ++strip) {
+        const int sx0 = wx0 + strip * strip_w, SW = min(strip_w, wx0 + W - sx0), total = SW * qrow;
+        if (strip) __syncthreads();                                  // the previous strip's sweep has read the window
+        {
+            uint4 *w4 = reinterpret_cast<uint4 *>(win);
+            for (int w = tid; w < (SW * Hp2) >> 2; w += blockDim.x) w4[w] = make_uint4(0u, 0u, 0u, 0u);   // H % 16 == 0: whole uint4s
+        }
+        __syncthreads();
+        STAMP(2);
+        // hits: the path's last cell is the endpoint cell (mapping.py:44-45)
+#pragma unroll
+        for (int j = 0; j < kOwnerRays; ++j) {
+            if (kind[j] == 0u) continue;
+            const unsigned wx = (unsigned)(pox[j] - sx0), wy = (unsigned)(poy[j] - wy0);
+            if (wx < (unsigned)SW && wy < (unsigned)H) {             // (the strips tile the bounding box clamped to the map)
+                atomicOr(&win[wx * Hp2 + (wy >> 1)], 0x8000u << ((wy & 1u) * 16u));
+                atomicAdd(&hit[(size_t)pox[j] * g.yw + poy[j]], 1u);
+                if (kind[j] == 3u) ++nvis;
+            }
+        }
+        // walk (bresenham.py:45-55): a ray continues from where it stands while it is in this strip
+#pragma unroll
+        for (int j = 0; j < kOwnerRays; ++j) {
+            OwnRay &o = ry[j];
+            const bool desc = kind[j] == 2u;
+            if (desc) {                                              // restarts from its first cell (which lies to the right)
+                Ray rr;
+                ray_setup(c0.pcx, c0.pcy, pox[j], poy[j], rr);
+                o.start(rr, H);
+            }
+            // the window halfword of the current cell, relative to this strip
+            o.h = (o.lx - sx0) * H + (o.ly - wy0);
+            // ascending: walks until it leaves the strip to the right; descending: until it has left it to the left
+            const int lo = desc ? sx0 : INT_MIN, hi = desc ? INT_MAX : sx0 + SW;
+            for (;;) {
+                bool moved = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                        // (four steps per wave-wide check; branch-free conditions)
+                    const bool act = (o.k <= o.kend) & (o.lx >= lo) & (o.lx < hi);
+                    moved |= act;
+                    if (act) {
+                        const bool cnt = ((unsigned)(o.lx - sx0) < (unsigned)SW) & (o.k != o.klast);
+                        if (cnt) atomicAdd(&win[o.h >> 1], 1u << ((o.h & 1) * 16));   // mapping.py:43
+                        o.error += o.derr;                           // bresenham.py:51
+                        const bool stepy = o.error >= 0.5;           // :53
+                        o.h += o.dh_k + (stepy ? o.dh_y : 0);
+                        o.lx += o.dlx_k + (stepy ? o.dlx_y : 0);
+                        o.error = stepy ? o.error - 1.0 : o.error;   // :55
+                        ++o.k;
+                    }
+                }
+                if (!__any(moved)) break;
+            }
+            o.ly = wy0 + (o.h - (o.lx - sx0) * H);                   // map y of the cell the ray stands on now
+        }
+        if (any_unsafe) {
+            // rays with cells outside the map: plain walk of the whole ray, counting this strip's cells
+#pragma unroll
+            for (int j = 0; j < kOwnerRays; ++j) {
+                if (kind[j] != 3u) continue;
+                Ray rr;
+                ray_setup(c0.pcx, c0.pcy, pox[j], poy[j], rr);
+                const int klast = rr.flag ? 0 : rr.dx;
+                double error = 0.0;
+                int y = rr.y0;
+                for (int k = 0; k <= rr.dx; ++k) {
+                    const int x = rr.x0 + k;
+                    const unsigned wx = (unsigned)((rr.steep ? y : x) - sx0), wy = (unsigned)((rr.steep ? x : y) - wy0);
+                    if (k != klast && wx < (unsigned)SW && wy < (unsigned)H) {
+                        ++nvis;
+                        atomicAdd(&win[wx * Hp2 + (wy >> 1)], 1u << ((wy & 1u) * 16u));
+                    }
+                    error += rr.derr;
+                    if (error >= 0.5) { y += rr.ystep; error -= 1.0; }
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(3);
+        // sweep: 4 lanes per 64-byte piece of a counter row
+        constexpr int kBatch = SLAM_SWEEP_BATCH;
+        for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
+            uint4 p[kBatch];
+            uint32_t om[kBatch], d0[kBatch], d1[kBatch];
+            size_t at[kBatch];
+            bool live[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int q = q0 + u * (int)blockDim.x;
+                d0[u] = d1[u] = 0u;
+                if (q < total) {
+                    const int r = (int)__umulhi((unsigned)q, qinv), c = q - r * qrow;
+                    const uint2 d = *reinterpret_cast<const uint2 *>(win + (r * Hp2 + 2 * c));
+                    d0[u] = d.x; d1[u] = d.y;
+                    at[u] = (size_t)(sx0 + r) * g.yw + (wy0 + 4 * c);
+                }
+                // the four lanes of a piece decide together (total and blockDim are multiples of 4)
+                const unsigned long long m = __ballot((d0[u] | d1[u]) != 0u);
+                live[u] = ((m >> (lane & 60)) & 0xFull) != 0ull;
+                if (live[u]) {
+                    p[u] = *reinterpret_cast<const uint4 *>(pass + at[u]);
+                    om[u] = *reinterpret_cast<const uint32_t *>(pm + at[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (!live[u]) continue;
+                const uint32_t d0v = d0[u], d1v = d1[u];
+                p[u].x += d0v & 0x7fffu; p[u].y += (d0v >> 16) & 0x7fffu; p[u].z += d1v & 0x7fffu; p[u].w += (d1v >> 16) & 0x7fffu;
+                *reinterpret_cast<uint4 *>(pass + at[u]) = p[u];
+                if (!(d0v | d1v)) continue;
+                const uint32_t o = om[u];
+                // one bit per byte (cell): touched by this scan / hit by this scan / occupied before (bit 6
+                // is set in 100 only) / never touched before (bit 4 is set in 50 only)
+                const uint32_t tb = ((d0v & 0xffffu) ? 1u : 0u) | ((d0v >> 16) ? 0x100u : 0u) | ((d1v & 0xffffu) ? 0x10000u : 0u) | ((d1v >> 16) ? 0x1000000u : 0u);
+                const uint32_t fb = ((d0v >> 15) & 1u) | (((d0v >> 31) & 1u) << 8) | (((d1v >> 15) & 1u) << 16) | ((d1v >> 31) << 24);
+                const uint32_t was = (o >> 6) & 0x01010101u, fresh = (o >> 4) & 0x01010101u;
+                const uint32_t pmax = max(max(p[u].x, p[u].y), max(p[u].z, p[u].w));
+                // a byte changes iff the cell was touched, was not occupied, and is fresh (50 -> 0 or 100),
+                // hit now (-> 100) or at / over the pass threshold now (-> 100)
+                if (((tb & ~was) & (fresh | fb)) != 0u || pmax >= pthr) {
+                    uint32_t occ = was | fb;
+                    occ |= (p[u].x >= pthr ? 1u : 0u) | (p[u].y >= pthr ? 0x100u : 0u) | (p[u].z >= pthr ? 0x10000u : 0u) | (p[u].w >= pthr ? 0x1000000u : 0u);
+                    const uint32_t tm = tb * 255u;
+                    const uint32_t out = (o & ~tm) | ((occ * 100u) & tm);
+                    if (out != o) *reinterpret_cast<uint32_t *>(pm + at[u]) = out;
+                }
+            }
+        }
+#ifdef SLAM_STAMPS
+        __syncthreads();
+#endif
+        STAMP(4);
+    }
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if (lane == 0) {
+        if (tot) atomicAdd(wg_visits, (unsigned long long)tot);
+        if (anybad) atomicOr(g.status, anybad);
+    }
+    __syncthreads();
+    if (tid == 0 && *wg_visits) atomicAdd(visit_slot(g.visits), *wg_visits);
+#ifdef SLAM_STAMPS
+    if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + 7, (unsigned long long)strips);
+#endif
+    STAMP_END(5);
+    lds_guard_check(guard, g.status);
+}
+
 template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
@@ -846,6 +1156,26 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     if (threads < SLAM_WIN_MIN_THREADS) threads = SLAM_WIN_MIN_THREADS;
     const int sort_cap = win_sort_cap((long)group * n);
     const int win_cells = win_cells_for(group, sort_cap);
+#ifndef SLAM_NO_OWNER_KERNEL
+    // one scan per map, cast by the map's only writer, live pmap, the reference's one-hit-occupies rule
+    if (exclusive && group == 1 && scans == 1 && g.hit_levels == 1 && (g.yw & 15) == 0 && (((size_t)g.xw * g.yw) & 3) == 0 &&
+        g.yw <= win_cells && n <= kOwnerMaxRays * kOwnerThreads) {
+        static bool own_attr[2] = {false, false};
+        if (!own_attr[which]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_owner<Src, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_owner<Src, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e != hipSuccess) return e;
+            own_attr[which] = true;
+        }
+        const size_t lds = win_lds_bytes(1, sort_cap, win_cells);
+        if (n <= kOwnerThreads) SLAM_LAUNCH((k_grid_update_owner<Src, 1>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
+        else                    SLAM_LAUNCH((k_grid_update_owner<Src, 2>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
+        return hipGetLastError();
+    }
+#endif
     SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
                 exclusive, sort_cap, win_cells);
     return hipGetLastError();

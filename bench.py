@@ -290,7 +290,7 @@ class ReplayWorkload:
 
 class ParticleWorkload:
     """configs[2]: slam_particles_dev on P hypotheses; maps persist (no reset), live pmap."""
-    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
+    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_owner", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args

@@ -230,3 +230,53 @@ def test_single_scan_owner_sweep_pass_threshold(slam):
     ctx.check_status()
     g.close()
     ctx.close()
+
+
+def _ring(x_lo, x_hi, y_lo, y_hi, step=1):
+    """Cells on the border of the box, all four sides."""
+    cells = [(x, y_lo) for x in range(x_lo, x_hi + 1, step)] + [(x, y_hi) for x in range(x_lo, x_hi + 1, step)]
+    cells += [(x_lo, y) for y in range(y_lo, y_hi + 1, step)] + [(x_hi, y) for y in range(y_lo, y_hi + 1, step)]
+    return cells
+
+
+@pytest.mark.parametrize("case", ["fits", "two_strips", "three_strips_many_rays", "leaves_map", "origin_outside", "too_many_rays"])
+def test_single_scan_owner_kernel_fans(slam, case):
+    """The single-scan owner kernel (one scan into a map with a live pmap: Mapping.update, the
+    particle maps): full-circle fans so that every octant, the reference's endpoint swap and
+    lines stepping towards -x occur; bounding boxes of one, two and three window strips; one and
+    two rays per lane; rays that leave the map; an origin outside the map; more rays than the
+    kernel takes (falls back to the group kernel).  Two passes: the second adds to non-zero
+    counters and meets a pmap that is no longer 50.  Everything must equal the oracle."""
+    xw, yw, scale, off_x, off_y = 440, 400, 20.0, 11.0, 10.0
+    org = (215, 203)
+    if case == "fits":
+        cells = _ring(150, 290, 120, 280, 2)                       # 141 x 161 cells: one strip, 1 ray per lane
+    elif case == "two_strips":
+        cells = _ring(60, 330, 90, 300, 3)                         # 271 x 211 -> 224-cell rows: two strips
+    elif case == "three_strips_many_rays":
+        cells = _ring(20, 420, 30, 370, 2)                         # 401 x 341: three strips, ~740 rays: 2 per lane
+    elif case == "leaves_map":
+        cells = _ring(-60, 500, -40, 450, 5)                       # every ray ends outside the map
+    elif case == "origin_outside":
+        org = (-30, 180)
+        cells = _ring(40, 300, 100, 320, 4) + [(-50, 181), (-30, 181)]
+    else:
+        cells = _ring(100, 400, 50, 350, 1)                        # 1 204 rays > 1 024
+    ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells])
+    oy = np.array([(c[1] + 0.5) / scale - off_y for c in cells])
+    cx, cy = (org[0] + 0.5) / scale - off_x, (org[1] + 0.5) / scale - off_y
+    ctx = slam.Context(0)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, context=ctx)
+    g.live_pmap()
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    for k in range(2):
+        g.update_host(ox, oy, cx, cy)
+        og.update(ox, oy, cx, cy)
+        ctx.check_status()
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt), (case, k, int(np.sum(r["pass"] != og.pass_cnt)))
+        assert np.array_equal(r["hit"], og.hit_cnt), (case, k)
+        assert np.array_equal(r["pmap"], og.pmap), (case, k, int(np.sum(r["pmap"] != og.pmap)))
+        assert g.visits() == og.visits, (case, k)
+    g.close()
+    ctx.close()
