@@ -280,3 +280,53 @@ def test_single_scan_owner_kernel_fans(slam, case):
         assert g.visits() == og.visits, (case, k)
     g.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["random_ranges", "inf_and_tiny", "span_270deg", "span_over_one_turn", "quantised_ties",
+                                  "near_origin", "n2", "n9", "n63", "nan_ranges", "f16_random", "f32_room"])
+def test_scan_window_nearest_neighbour_edge_scans(slam, syn, case):
+    """The beam-window nearest-neighbour search of scan targets (nn_polar) must give the exhaustive
+    scan's answer whatever the scans look like: unstructured ranges (wide windows: the box search
+    takes over), inf / tiny ranges, a 270-degree lidar (no wrap), more than one turn (not a usable
+    scan: boxes), quantised ranges (exact ties across beams), queries next to the origin, tiny
+    scans, NaN ranges, reduced point storage.  Iteration counts exact, transforms to 1e-9."""
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    amin, amax, n, scans, points = AMIN, AMAX, 360, 12, "f64"
+    if case in ("random_ranges", "f16_random"):
+        ranges = rng.uniform(0.1, 30.0, size=(scans, n))
+        points = "f16" if case == "f16_random" else "f64"
+    elif case == "inf_and_tiny":
+        ranges = syn.make_replay(scans, n, seed=5, stride=5).ranges.astype(np.float64)
+        ranges[:, ::7] = np.inf
+        ranges[:, 3::11] = 0.1
+    elif case == "span_270deg":
+        amin, amax = -2.356, 2.356
+        ranges = syn.make_replay(scans, n, seed=6, stride=5).ranges.astype(np.float64)
+    elif case == "span_over_one_turn":
+        amin, amax = -4.0, 4.0
+        ranges = syn.make_replay(scans, n, seed=7, stride=5).ranges.astype(np.float64)
+    elif case == "quantised_ties":
+        ranges = np.round(syn.make_replay(scans, n, seed=8, stride=5).ranges.astype(np.float64) * 2.0) / 2.0 + 0.5
+    elif case == "near_origin":
+        ranges = rng.uniform(0.1, 0.3, size=(scans, n))
+    elif case in ("n2", "n9", "n63"):
+        n = int(case[1:])
+        ranges = syn.make_replay(scans, n, seed=9, stride=5).ranges.astype(np.float64)
+    elif case == "nan_ranges":
+        ranges = syn.make_replay(scans, n, seed=10, stride=5).ranges.astype(np.float64)
+        ranges[2, 50] = np.nan
+        ranges[5, 300:304] = np.nan
+    else:
+        ranges = syn.make_replay(scans, n, seed=11, stride=5).ranges.astype(np.float64)
+        points = "f32"
+    ranges = ranges.astype(np.float32)
+    poses, T, it = slam.replay_host(ranges, amin, amax, dtype=points)
+    oposes, oT, oit, _ = checks.replay_reference(ranges, amin, amax, None, points, 30, 1e-3, threads=8)
+    assert np.array_equal(it, oit), (case, it, oit)
+    assert np.allclose(T, oT.reshape(T.shape), rtol=0, atol=FTOL, equal_nan=True), case
+    assert np.allclose(poses, oposes, rtol=0, atol=1e-8, equal_nan=True), case
+    # the matcher's stand-alone operator on the same clouds (point buffers: the box search) agrees too
+    pts = np.stack([np.array(co.laser_to_points(r, amin, amax)) for r in ranges])
+    if points == "f64" and case != "nan_ranges":
+        Tb, itb, _ = slam.icp_batch_host(pts[:-1], pts[1:], 30, 1e-3)
+        assert np.array_equal(itb, it) and np.max(np.abs(Tb - T)) < FTOL, case
