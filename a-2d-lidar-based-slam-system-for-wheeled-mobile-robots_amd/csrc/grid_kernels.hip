@@ -1297,7 +1297,51 @@ __global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratc
         rec.flags = 0; rec.x0 = rec.y0 = rec.dx = rec.yend = 0; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
         int pox, poy, b2 = 0;
         Ray ry;
-        if (src.ray(l, s, i, sc, g, pox, poy, b2) && ray_setup(sc.pcx, sc.pcy, pox, poy, ry)) {
+        const bool valid = src.ray(l, s, i, sc, g, pox, poy, b2) && ray_setup(sc.pcx, sc.pcy, pox, poy, ry);
+        // the common ray: recorded, and both ends (hence every cell) inside the map.  Only the walk's
+        // decisions are needed - one bit per step - so the loop is the error recurrence alone
+        // (bresenham.py:51-55), all lanes at the same step; the path's last cell is the endpoint cell
+        // itself and takes its hit without being walked to (mapping.py:44-45).
+        const bool plain = valid && ry.dx < kTileSteps && (unsigned)sc.pcx < (unsigned)g.xw && (unsigned)sc.pcy < (unsigned)g.yw &&
+                           (unsigned)pox < (unsigned)g.xw && (unsigned)poy < (unsigned)g.yw;
+        {
+            uint32_t *bw = ts.bits + rid * kTileWords;
+            unsigned short *pw = ts.prefix + rid * kTileWords;
+            const int dx = plain ? ry.dx : -1;
+            const double derr = plain ? ry.derr : 0.0;
+            double error = 0.0;
+            uint32_t count = 0, before_last = 0;
+            for (int k0 = 0; __any(k0 <= dx); k0 += 32) {
+                if (k0 <= dx) {
+                    uint32_t word = 0;
+                    const int nb = min(32, dx - k0 + 1);
+#pragma unroll 8
+                    for (int b = 0; b < 32; ++b) {
+                        if (b < nb) {
+                            error += derr;                            // bresenham.py:51
+                            const bool stepy = error >= 0.5;          // :53
+                            error = stepy ? error - 1.0 : error;      // :55
+                            word |= stepy ? (1u << b) : 0u;
+                        }
+                    }
+                    pw[k0 >> 5] = (unsigned short)count;
+                    bw[k0 >> 5] = word;
+                    if (k0 + 32 > dx) before_last = count + __popc(word & ((1u << (dx - k0)) - 1u));   // y advances before step dx
+                    count += __popc(word);
+                }
+            }
+            if (plain) {
+                nvis += (unsigned)ry.dx + 1u;                         // mapping.py:41: every cell is in the map
+                atomicAdd(&hit[(size_t)pox * g.yw + poy], 1u);
+                rec.yend = ry.y0 + ry.ystep * (int)before_last;
+                rec.x0 = ry.x0; rec.y0 = ry.y0; rec.dx = ry.dx;
+                rec.flags = 8u | (ry.steep ? 1u : 0u) | (ry.flag ? 2u : 0u) | (ry.ystep > 0 ? 4u : 0u);
+                int a0 = ry.x0, a1 = ry.x0 + ry.dx, b0 = min(ry.y0, rec.yend), b1 = max(ry.y0, rec.yend);
+                int mx0 = ry.steep ? b0 : a0, mx1 = ry.steep ? b1 : a1, my0 = ry.steep ? a0 : b0, my1 = ry.steep ? a1 : b1;
+                atomicMin(&box[0], mx0); atomicMin(&box[1], my0); atomicMax(&box[2], mx1); atomicMax(&box[3], my1);
+            }
+        }
+        if (valid && !plain) {                                       // leaves the map, or too long to record: the step-by-step form
             const bool record = ry.dx < kTileSteps;
             const int klast = ry.flag ? 0 : ry.dx;
             uint32_t *bw = ts.bits + rid * kTileWords;
