@@ -399,6 +399,8 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // ---------------------------------------------------------------------------------
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
+constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collapsed-set exchange (two parities)
+
 template <typename T, int QPT>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 {
@@ -408,8 +410,9 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
     Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
     double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][5][kMaxWaves]
-    unsigned *geo = reinterpret_cast<unsigned *>(red + 2 * 5 * kMaxWaves);                       // [4] polar_probe
-    char *guard = smem + nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + 16;
+    unsigned *geo = reinterpret_cast<unsigned *>(red + 2 * 5 * kMaxWaves);                       // [4] polar_probe; geo[3]: source set collapsed
+    double *cref = reinterpret_cast<double *>(geo + 4);                                          // [2][4]: matched point of query 0, "all the same" flag
+    char *guard = smem + nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + kIcpExtraLds;
     lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         src.pts = static_cast<const T *>(a.src) + be * a.src_stride;
     }
 
-    if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; }
+    if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; }
     stage_target(tar, n_tar, tarL, boxes, boxes4);                   // (barriers inside: geo is initialised for the probe)
 #ifndef SLAM_NO_POLAR
     if (a.ranges) polar_probe(tar, n_tar, geo);
@@ -450,7 +453,23 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         sy[q] = ay[q] = y;
         seed[q] = i;                             // first guess: the same beam index
     }
+    {
+        // Collapsed sets (every point of a set is ONE point): W = BB^T.AA is mathematically zero and
+        // the canonical answer is R = I (the SVD of a zero matrix), t = centroid_B - centroid_A.  The
+        // reference's centred rows are rounding noise there (np.mean of n equal values is not that
+        // value) and its rotation arbitrary: documented deviation, tests/golden/g8_collapsed.npz.
+        double2 p0 = src.at(0);
+        if (a.prior) {
+            const double *p = a.prior + 6 * (long)b;
+            p0 = make_double2(p[0] * p0.x + p[1] * p0.y + p[2], p[3] * p0.x + p[4] * p0.y + p[5]);
+        }
+        bool differs = false;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) differs |= ok[q] && !(ax[q] == p0.x && ay[q] == p0.y);
+        if (differs) geo[3] = 0u;
+    }
     __syncthreads();
+    const bool src_collapsed = geo[3] != 0u;
     // the target is a scan with usable beam geometry: nearest neighbours by beam window (nn_polar)
     PolarGeo pg;
     {
@@ -495,17 +514,28 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         // Two passes, as the reference (centroids, then centred products, icp.py:154-160): when
         // every source point matches the same target the centred products are exactly zero and
         // R falls back to the identity, which one-pass raw moments would turn into rounding noise.
-        block_sum<5>(v, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+        par ^= 1;
+        double *cr = cref + 4 * (it & 1);          // alternates per iteration: two barriers lie between a slot's reuse
+        if (nwaves > 1 && tid == 0) { cr[0] = mx[0]; cr[1] = my[0]; cr[2] = 1.0; }   // (query 0 of thread 0 always exists)
+        block_sum<5>(v, red + par * 5 * kMaxWaves, nwaves, wave, lane);
         double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;   // icp.py:154-155
         double w[4] = {0, 0, 0, 0};
+        // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above
+        const double m0x = nwaves > 1 ? cr[0] : readlane_f64(mx[0], 0), m0y = nwaves > 1 ? cr[1] : readlane_f64(my[0], 0);
+        bool differs = false;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             if (ok[q]) {
                 double aax = sx[q] - cax, aay = sy[q] - cay, bbx = mx[q] - cbx, bby = my[q] - cby;
                 w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;   // :160
+                differs |= !(mx[q] == m0x && my[q] == m0y);
             }
         }
-        block_sum<4>(w, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+        if (nwaves > 1 && differs) cr[2] = 0.0;
+        par ^= 1;
+        block_sum<4>(w, red + par * 5 * kMaxWaves, nwaves, wave, lane);
+        const bool tar_collapsed = nwaves > 1 ? cr[2] != 0.0 : !__any(differs);
+        if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);    // :69
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {                              // src = T.src (:71)
@@ -535,6 +565,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         }
     }
     block_sum<4>(w, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+    if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
     if (tid == 0) {
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = a.T_out + 9 * (long)b;
@@ -564,7 +595,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // (a handful of pairs cannot fill the chip anyway: one query per lane gives the lowest latency,
     // 0.13 instead of 0.15 ms for the drop-in ICP.process call)
     if (a.B > 64 && qpt < SLAM_ICP_QPT_PREF && a.n_src > 64 * SLAM_ICP_QPT_PREF) qpt = SLAM_ICP_QPT_PREF;   // queries per lane: fewer waves per pair, cheaper reductions (measured: 3 beats 2 by 3.5 % when replays overlap, 2 beats 1 by 8 % alone)
-    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + 16 + kLdsGuard;
+    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + kIcpExtraLds + kLdsGuard;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q)                                                                                        \
@@ -659,11 +690,18 @@ hipError_t launch_nn(const void *src, const void *tar, int B, int n_src, int n_t
 __global__ void __launch_bounds__(256) k_kabsch(const double *src, const double *tar, int n, double *T_out)
 {
     __shared__ double red[2 * 4 * kMaxWaves];
+    __shared__ int same[2];                                          // every row of src / of tar is ONE point (see k_icp)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     const double *a = src + (long)b * 2 * n, *bb = tar + (long)b * 2 * n;
+    if (tid == 0) same[0] = same[1] = 1;
+    __syncthreads();
     double v[4] = {0, 0, 0, 0};
-    for (int i = tid; i < n; i += blockDim.x) { v[0] += a[i]; v[1] += a[n + i]; v[2] += bb[i]; v[3] += bb[n + i]; }
+    for (int i = tid; i < n; i += blockDim.x) {
+        v[0] += a[i]; v[1] += a[n + i]; v[2] += bb[i]; v[3] += bb[n + i];
+        if (!(a[i] == a[0] && a[n + i] == a[n])) same[0] = 0;
+        if (!(bb[i] == bb[0] && bb[n + i] == bb[n])) same[1] = 0;
+    }
     block_sum<4>(v, red, nwaves, wave, lane);
     double dn = (double)n;
     double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
@@ -673,6 +711,7 @@ __global__ void __launch_bounds__(256) k_kabsch(const double *src, const double 
         w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
     }
     block_sum<4>(w, red + 4 * kMaxWaves, nwaves, wave, lane);
+    if (same[0] || same[1]) w[0] = w[1] = w[2] = w[3] = 0.0;          // collapsed set: canonical R = I (barriers of block_sum passed)
     if (tid == 0) {
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = T_out + 9 * (long)b;

@@ -23,7 +23,7 @@ seeded synthetic inputs, and only the inputs and outputs are written out.
                           laserEstimation, calc_map_observation, the pose filter and the whole
                           Localization.laserCallback.
 
-Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,...,g7]
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,...,g8]
 """
 from __future__ import annotations
 
@@ -653,14 +653,48 @@ def gen_g7(ref, out_dir):
     save(out_dir, "g7_w12_node.npz", **arrays)
 
 
+# ----------------------------------------------------------------------------
+# G8  collapsed correspondences (every source point matched to ONE target point)
+# ----------------------------------------------------------------------------
+def gen_g8(ref, out_dir):
+    """W12m/icp.py:149-179 when every row of the target set is one point: the centred target
+    rows are rounding noise (np.mean of n equal values is not that value), W ~ 1e-31, and the
+    rotation the reference extracts from its SVD is arbitrary (but deterministic).  The product
+    and the oracles return the canonical answer R = I, t = centroid_B - centroid_A for this case;
+    these vectors record what the reference itself returns, so that the difference is pinned."""
+    with quiet():
+        icp = ref.icp.ICP()
+    rng = np.random.default_rng(5)
+    src_l, tar_l, T_l, Tp_l, it_l, cloud_l = [], [], [], [], [], []
+    ICPc = type("ICPc8", (_Counting, ref.icp.ICP), {})
+    with quiet():
+        icpc = ICPc()
+    ones = lambda a: np.vstack([a, np.ones((1, a.shape[1]))])
+    for c in range(8):
+        tar3 = np.array([[0.3, 103.1, 211.7], [0.7, 97.3, -54.9]]) + rng.normal(0, 0.01, size=(2, 3))
+        n = 24
+        src = tar3[:, :1] + rng.normal(0, 0.2, size=(2, n))
+        d, idx = icp.findNearest(src.T, tar3.T)
+        assert set(idx.tolist()) == {0}
+        with quiet():
+            T = icp.getTransform(src.T, tar3.T[idx])              # paired rows: all target rows equal
+            icpc.max_iter, icpc.nn_calls = 30, 0
+            sys.modules["rospy"].get_param = lambda name, default=None: PARAMS.get(name, default)
+            Tp = icpc.process(ones(tar3), ones(src))
+        src_l.append(src), tar_l.append(tar3.T[idx].T.copy()), T_l.append(T), Tp_l.append(Tp), it_l.append(icpc.nn_calls)
+        cloud_l.append(tar3)
+    save(out_dir, "g8_collapsed.npz", src=np.array(src_l), tar_rows=np.array(tar_l), T_ref=np.array(T_l),
+         cloud=np.array(cloud_l), process_T_ref=np.array(Tp_l), process_iters_ref=np.array(it_l, dtype=np.int32))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7,g8")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference()
-    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6), ("g7", gen_g7)):
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6), ("g7", gen_g7), ("g8", gen_g8)):
         if name in args.only.split(","):
             t0 = time.time()
             fn(ref, args.out)

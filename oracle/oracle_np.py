@@ -86,6 +86,17 @@ def find_nearest(src, tar):
 # ----------------------------------------------------------------------------
 # a-5  2-D Kabsch via 2x2 SVD
 # ----------------------------------------------------------------------------
+def collapsed(rows):
+    """True when every row of the set is ONE point (bitwise).  Then W = BB^T.AA is
+    mathematically zero and every rotation is optimal; the reference's centred rows are
+    rounding noise instead (np.mean of n equal values is not that value), W ~ 1e-31, and the
+    rotation its SVD returns is arbitrary.  DOCUMENTED DEVIATION: the oracles and the product
+    return the canonical R = I, t = centroid_B - centroid_A (the SVD of an exact zero matrix);
+    tests/golden/g8_collapsed.npz records what the reference itself returns."""
+    rows = np.asarray(rows)
+    return rows.shape[0] > 0 and bool(np.all(rows == rows[0]))
+
+
 def get_transform(src, tar):
     """W12m/icp.py:149-179.  src, tar [N,2] paired rows -> T 3x3.  Uses the
     ``Vt[1,:]`` reflection fix of the W12 generation (:168); W7/icp.py:136 indexes
@@ -95,6 +106,8 @@ def get_transform(src, tar):
     aa = src - centroid_a
     bb = tar - centroid_b
     w = np.dot(bb.transpose(), aa)
+    if collapsed(src) or collapsed(tar):
+        w = np.zeros((2, 2))          # documented canonical answer, see collapsed()
     u, _s, vt = np.linalg.svd(w)
     r = np.dot(u, vt)
     if np.linalg.det(r) < 0:
@@ -117,6 +130,8 @@ def get_transform_closed_form(src, tar):
     aa = src - ca
     bb = tar - cb
     w = np.dot(bb.transpose(), aa)
+    if collapsed(src) or collapsed(tar):
+        w = np.zeros((2, 2))
     a = w[0, 0] + w[1, 1]
     b = w[1, 0] - w[0, 1]
     h = math.hypot(a, b)

@@ -94,6 +94,20 @@ void orc_get_transform(const double *ax, const double *ay, const double *bx, con
         double aax = ax[k] - cax, aay = ay[k] - cay, bbx = bx[k] - cbx, bby = by[k] - cby;
         w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
     }
+    /* DOCUMENTED DEVIATION (collapsed sets): when every row of a or of b is ONE point, W is
+     * mathematically zero and every rotation is optimal; the reference's centred rows are
+     * rounding noise instead (np.mean of n equal values is not that value), W ~ 1e-31, and
+     * the rotation its SVD returns is arbitrary.  Oracles and product return the canonical
+     * R = I, t = centroid_B - centroid_A (the SVD of an exact zero matrix);
+     * tests/golden/g8_collapsed.npz records what the reference itself returns. */
+    {
+        int same_a = 1, same_b = 1;
+        for (int k = 1; k < n; ++k) {
+            if (!(ax[k] == ax[0] && ay[k] == ay[0])) same_a = 0;
+            if (!(bx[k] == bx[0] && by[k] == by[0])) same_b = 0;
+        }
+        if (same_a || same_b) w[0] = w[1] = w[2] = w[3] = 0.0;
+    }
     double u[4], s[2], vt[4], r[4];
     svd2x2(w, u, s, vt);                                          /* :161 */
     r[0] = u[0] * vt[0] + u[1] * vt[2]; r[1] = u[0] * vt[1] + u[1] * vt[3];
