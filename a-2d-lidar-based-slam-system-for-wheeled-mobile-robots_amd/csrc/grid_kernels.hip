@@ -404,7 +404,7 @@ template <bool COVERS, class Src>
 __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, const ScanConst *sc, int l, int s0, int n,
                                               int nrays, int *next_ray, const unsigned short *order, unsigned *win, int wx0,
                                               int wy0, int W, int H, int Hp2, uint32_t *__restrict__ pass,
-                                              uint32_t *__restrict__ hit)
+                                              uint32_t *__restrict__ hit, int first_bad)
 {
     unsigned nvis = 0;
     const int lane = threadIdx.x & 63;
@@ -417,6 +417,7 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
         const int r = order ? (int)order[base + lane] : base + lane;   // longest rays first when sorted
         int s = r / n, i = r - s * n, pox, poy, b2 = 0;
         Ray ry;
+        if (i >= first_bad) continue;                                // (single scan) beams from the first bad one on are not cast
         if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
         if (!ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry)) continue;
         const int klast = ry.flag ? 0 : ry.dx;                       // walk step of the path's LAST cell
@@ -454,7 +455,8 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
 template <class Src>
 __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src &src, const ScanConst &sc, int l, int s0,
                                                     int nrays, int *next_ray, const unsigned short *order, unsigned *win,
-                                                    int wx0, int wy0, int W, int H, int Hp2, uint32_t *__restrict__ hit)
+                                                    int wx0, int wy0, int W, int H, int Hp2, uint32_t *__restrict__ hit,
+                                                    int first_bad)
 {
     unsigned nvis = 0;
     const int lane = threadIdx.x & 63;
@@ -467,6 +469,7 @@ __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src 
         const int i = order ? (int)order[base + lane] : base + lane;   // longest rays first when sorted
         int pox, poy, b2 = 0;
         Ray ry;
+        if (i >= first_bad) continue;                                // beams from the first bad one on are not cast
         if (!src.ray(l, s0, i, sc, g, pox, poy, b2)) continue;
         if (max(sc.pcx, pox) < wx0 || min(sc.pcx, pox) >= wx0 + W) continue;   // never enters this strip
         if (!ray_setup(sc.pcx, sc.pcy, pox, poy, ry)) continue;
@@ -540,7 +543,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const bool fused = exclusive && g.pmap_live && (g.yw & 3) == 0 && (((size_t)gi * g.xw * g.yw) & 3) == 0;
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
     unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
-    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; }
+    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; box[15] = INT_MAX; }
     const bool sorted = nrays <= sort_cap;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
     if (tid < kSortBins) hist[tid] = 0;
@@ -550,12 +553,17 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // pass 1: bounding box of everything the group's rays can touch
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
     for (int r = tid; r < nrays; r += blockDim.x) {
-        int s = r / n, i = r - s * n, pox, poy, len = 0;
-        if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, bad)) {
+        int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0;
+        if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) {
             bx0 = min(bx0, min(pox, sc[s].pcx)); bx1 = max(bx1, max(pox, sc[s].pcx));
             by0 = min(by0, min(poy, sc[s].pcy)); by1 = max(by1, max(poy, sc[s].pcy));
             len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
         }
+        // a single scan stops at its first beam that Python's int() would raise on (mapping.py:29-36:
+        // the beams before it have been applied when the exception leaves update(), and the error is
+        // that beam's); a group of scans reports any bad beam and casts all the others
+        if (cnt == 1) { if (b2) atomicMin(&box[15], i); }
+        else bad |= b2;
         if (sorted) {                                                // bin by length, longest first
             int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);
             bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
@@ -568,6 +576,11 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     }
     __syncthreads();
     if (tid == 0) {
+        if (box[15] != INT_MAX) {                                    // the first bad beam's own error (NaN or overflow)
+            int pox, poy, b2 = 0;
+            (void)src.ray(l, s0, box[15], sc[0], g, pox, poy, b2);
+            atomicOr(g.status, b2);
+        }
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         int W = 0, H = 0, covers = 1;
         int fastwin = 0, strip_w = 0;                                // strips of the single-scan owner form
@@ -632,8 +645,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         __syncthreads();
         STAMP(2);                                   // sort + zero
         // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
-        if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
-        else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit);
+        const int first_bad = box[15];
+        if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
+        else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
         __syncthreads();
         STAMP(3);                                   // walk
     }
@@ -681,7 +695,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         if (tid == 0) box[9] = 0;
         __syncthreads();
         STAMP(2);                                   // (sort +) zero
-        nvis += cast_rays_strip(g, src, sc[0], l, s0, nrays, &box[9], ord, win, sx0, wy0, SW, H, Hp2, hit);
+        nvis += cast_rays_strip(g, src, sc[0], l, s0, nrays, &box[9], ord, win, sx0, wy0, SW, H, Hp2, hit, box[15]);
         __syncthreads();
         STAMP(3);                                   // walk
         for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
@@ -889,7 +903,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
 
     if (tid == 0) {
         src.scan_const(l, 0, g, sc[0]);
-        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; *wg_visits = 0ull; box[14] = 0;
+        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; *wg_visits = 0ull; box[14] = 0; box[15] = INT_MAX;
     }
     if (tid < kSortBins) hist[tid] = 0;
     __syncthreads();
@@ -899,12 +913,16 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     // pass 1: endpoints, bounding box, length histogram
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
     for (int r = tid; r < n; r += blockDim.x) {
-        int pox, poy, len = 0;
-        if (src.ray(l, 0, r, c0, g, pox, poy, bad)) {
+        int pox, poy, len = 0, b2 = 0;
+        if (src.ray(l, 0, r, c0, g, pox, poy, b2)) {
             bx0 = min(bx0, min(pox, c0.pcx)); bx1 = max(bx1, max(pox, c0.pcx));
             by0 = min(by0, min(poy, c0.pcy)); by1 = max(by1, max(poy, c0.pcy));
             len = max(abs(pox - c0.pcx), abs(poy - c0.pcy));
         }
+        // the scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the
+        // beams before it have been applied when the exception leaves update(), and the error is that
+        // beam's)
+        if (b2) atomicMin(&box[15], r);
         int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);      // longest first
         bins[r] = (unsigned short)bin;
         atomicAdd(&hist[bin], 1);
@@ -915,6 +933,11 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     }
     __syncthreads();
     if (tid == 0) {
+        if (box[15] != INT_MAX) {                                    // the first bad beam's own error (NaN or overflow)
+            int pox, poy, b2 = 0;
+            (void)src.ray(l, 0, box[15], c0, g, pox, poy, b2);
+            atomicOr(g.status, b2);
+        }
         // window = bounding box clamped to the map, rows widened to whole 16-cell pieces, cut into
         // S strips of at most Ws rows that each fit the window
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
@@ -958,6 +981,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
         const int sr = tid + j * (int)blockDim.x;
         if (sr >= n || strips == 0) continue;
         int b2 = 0;
+        if ((int)order[sr] >= box[15]) continue;                     // at or after the first bad beam: not cast
         if (!src.ray(l, 0, (int)order[sr], c0, g, pox[j], poy[j], b2)) continue;
         if (!ray_setup(c0.pcx, c0.pcy, pox[j], poy[j], rr)) continue;          // identical cells: empty path (bresenham.py:10-11)
         const bool inmap = (unsigned)c0.pcx < (unsigned)g.xw && (unsigned)c0.pcy < (unsigned)g.yw &&

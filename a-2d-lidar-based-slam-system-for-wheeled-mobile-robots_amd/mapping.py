@@ -20,7 +20,7 @@ Fidelity notes:
   hits-first order (include/slam_hip.h, slam_grid_create).
 * NaN coordinates raise ``ValueError`` and infinite ``oy`` / centre raise ``OverflowError``
   as ``int()`` does in the reference.  The reference stops at the offending beam (earlier
-  beams are already in the map); here every other beam of the call is applied.  A cell index
+  beams are already in the map, later ones are not); so does ``update``.  A cell index
   beyond 2^20 also raises ``OverflowError`` (the reference would walk that ray for hours).
 """
 from __future__ import annotations
@@ -107,7 +107,7 @@ class Mapping:
             _abi.check(L.slam_grid_update(self._ctx.handle, self._grid, _abi.ptr(ox), _abi.ptr(oy), _abi.ptr(cx),
                                           _abi.ptr(cy), 1, n, None))
         finally:
-            self._datamap_stale = True            # on a NaN / inf beam the other beams were still applied
+            self._datamap_stale = True            # on a NaN / inf beam the beams before it were still applied
         return self._fetch_pmap()
 
     def update_scans(self, ranges, angle_min, angle_max, poses, centres=None):

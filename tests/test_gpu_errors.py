@@ -77,3 +77,33 @@ def test_python_layer_maps_error_codes(env):
         m.update([0.0], [float("inf")], 0.0, 0.0)
     m.update([0.5], [0.5], 0.0, 0.0)                              # the sticky flag was cleared
     assert m.pmap.max() == 100
+
+
+@pytest.mark.parametrize("xw,live", [(200, False), (400, True), (400, False)])
+@pytest.mark.parametrize("bad_value", [float("nan"), float("inf")])
+def test_map_state_after_a_raising_beam_equals_the_references(env, xw, live, bad_value):
+    """mapping.py:29-36 raises at the first beam whose coordinate int() cannot convert, with the
+    beams before it applied and none after it.  A single-scan update leaves exactly that map
+    (window kernel on the reference's 200 x 200 map, owner kernel with a live pmap)."""
+    from oracle import c_oracle as co
+    slam, A, L, ctx = env
+    rng = np.random.default_rng(11)
+    n, i_bad = 90, 37
+    scale = 10.0 if xw == 200 else 20.0
+    ang = np.linspace(-3.1, 3.1, n)
+    r = rng.uniform(2.0, 8.0, size=n)
+    ox, oy = r * np.cos(ang), r * np.sin(ang)
+    ox[5] = np.inf                                               # skipped beam (only ox is tested, :30): no error
+    oy[i_bad] = bad_value                                        # raises here (nan: ValueError, inf: OverflowError)
+    oy[i_bad + 9] = np.nan                                       # never reached
+    g = slam.DeviceGrid(1, xw, xw, scale, 10.0, 10.0, context=ctx)
+    if live:
+        g.live_pmap()
+    with pytest.raises(ValueError if np.isnan(bad_value) else OverflowError):   # what int() raises in the reference
+        g.update_host(ox, oy, 0.25, -0.4)
+    og = co.Grid(xw, xw, scale, 10.0, 10.0)
+    og.update(ox[:i_bad], oy[:i_bad], 0.25, -0.4)                # the reference's state when the exception leaves update()
+    got = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(got["pass"], og.pass_cnt) and np.array_equal(got["hit"], og.hit_cnt)
+    assert np.array_equal(got["pmap"], og.pmap) and g.visits() == og.visits
+    g.close()
