@@ -97,27 +97,43 @@ def all_reduce_grid(grid):
     dist.all_reduce(h, op=dist.ReduceOp.SUM)
 
 
-def hip_runner(ranges, angle_min, angle_max, max_iter, tolerance, local_rank):
-    """Default compute: this rank's trajectories on its GPU (DeviceReplay, no map)."""
+def hip_runner(ranges, angle_min, angle_max, max_iter, tolerance, local_rank, maps=None):
+    """Default compute: this rank's trajectories on its GPU (DeviceReplay): scan matching, dead
+    reckoning and - with ``maps=(xw, yw, reso)`` - one occupancy map per trajectory, as
+    BASELINE.json configs[3] runs them.  Returns poses, or (poses, pmaps [L, xw, yw] int8)."""
     from .replay import DeviceReplay
-    dr = DeviceReplay(ranges, angle_min, angle_max, max_iter=max_iter, tolerance=tolerance, device=local_rank)
+    ranges = np.asarray(ranges, dtype=np.float32)
+    L = ranges.shape[0] if ranges.ndim == 3 else 1
+    dr = DeviceReplay(ranges, angle_min, angle_max, max_iter=max_iter, tolerance=tolerance, device=local_rank,
+                      grid_of_traj=list(range(L)) if maps else None)
+    grid = dr.make_grid(L, int(maps[0]), int(maps[1]), float(maps[2])) if maps else None
     dr.run()
     poses, _T, _it = dr.results()
-    return poses
+    if not maps:
+        return poses
+    pmaps = np.stack([grid.read(g, want=("pmap",))["pmap"] for g in range(L)])
+    return poses, pmaps
 
 
 def replay_sharded(make_ranges, n_traj, angle_min, angle_max, max_iter=30, tolerance=0.001, runner=hip_runner,
-                   backend=None):
+                   backend=None, maps=None):
     """Replay ``n_traj`` independent scan streams over all ranks.
 
     ``make_ranges(i)`` returns trajectory i's float32 ranges [n_scan, n]; each rank only
-    materialises its own block.  Returns (final_poses [n_traj, 3] on every rank,
+    materialises its own block.  ``maps=(xw, yw, reso)``: every trajectory also builds its
+    occupancy map (they stay on their rank; ``replay_sharded.local_maps`` holds this rank's
+    [L_local, xw, yw] int8 afterwards).  Returns (final_poses [n_traj, 3] on every rank,
     local_poses [L_local, n_scan-1, 3], (lo, hi))."""
     rank, world, local = init(backend)
     lo, hi = shard_range(n_traj, rank, world)
+    replay_sharded.local_maps = None
     if hi > lo:
         ranges = np.stack([np.asarray(make_ranges(i), dtype=np.float32) for i in range(lo, hi)])
-        poses = np.asarray(runner(ranges, angle_min, angle_max, max_iter, tolerance, local))
+        if maps:
+            poses, replay_sharded.local_maps = runner(ranges, angle_min, angle_max, max_iter, tolerance, local, maps=maps)
+            poses = np.asarray(poses)
+        else:
+            poses = np.asarray(runner(ranges, angle_min, angle_max, max_iter, tolerance, local))
         finals = poses[:, -1, :]
     else:
         poses, finals = np.zeros((0, 0, 3)), np.zeros((0, 3))

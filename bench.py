@@ -190,7 +190,17 @@ def load_pmc(config, kernel):
     except Exception:
         return {}
     d = d.get(config, d if config == "replay" else {})
-    return d.get(kernel, {}) if isinstance(d, dict) else {}
+    if not isinstance(d, dict):
+        return {}
+    if "+" in kernel:          # a family of kernels launched back to back: byte and instruction counts add up
+        parts = [d.get(k, {}) for k in kernel.split("+")]
+        if not all(parts):
+            return {}
+        out = {"source": parts[0].get("source")}
+        for key in ("hbm_bytes_per_launch", "valu_insts_per_launch", "lds_insts_per_launch"):
+            out[key] = sum(p.get(key) or 0.0 for p in parts)
+        return out
+    return d.get(kernel, {})
 
 
 # --------------------------------------------------------------------------------------
@@ -228,8 +238,8 @@ class ReplayWorkload:
         self.done = 0
         self.L = slam._abi.lib()
         self.units_per_step = self.lanes[0].dr.scans_per_run
-        if self.tiled():
-            self.family_kernels = dict(self.family_kernels, grid="k_tile_cast")
+        if self.tiled():      # the tiled ray cast is two kernels timed as one family (recorded walks, then tiles)
+            self.family_kernels = dict(self.family_kernels, grid="k_ray_bits+k_tile_cast")
 
     def tiled(self):
         a = self.args

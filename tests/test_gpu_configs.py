@@ -195,11 +195,17 @@ def test_dist_replay_sharded_world1_hip_runner(slam, syn):
     """dist.replay_sharded with the HIP runner (the multi-GPU entry of configs[3]) on one
     rank: same poses as the oracle, gathered result == local result."""
     reps = [syn.make_replay(60, 360, seed=10 + i, stride=5) for i in range(3)]
-    finals, local, (lo, hi) = slam.dist.replay_sharded(lambda i: reps[i].ranges, 3, AMIN, AMAX)
+    finals, local, (lo, hi) = slam.dist.replay_sharded(lambda i: reps[i].ranges, 3, AMIN, AMAX, maps=(400, 400, 0.05))
     assert (lo, hi) == (0, 3) and finals.shape == (3, 3) and local.shape == (3, 59, 3)
+    maps = slam.dist.replay_sharded.local_maps
+    assert maps.shape == (3, 400, 400)
     for i in range(3):
-        op, _, _, _ = co.replay(reps[i].ranges, AMIN, AMAX, None, threads=8)
+        og = checks.metric_grid(400, 400, 0.05)
+        op, _, _, _ = co.replay(reps[i].ranges, AMIN, AMAX, og, threads=8)
         assert np.max(np.abs(local[i] - op)) < FTOL and np.array_equal(finals[i], local[i, -1])
+        assert np.array_equal(maps[i], og.pmap), i               # every trajectory's own map
+    finals2, local2, _ = slam.dist.replay_sharded(lambda i: reps[i].ranges, 3, AMIN, AMAX)   # without maps: same poses
+    assert np.array_equal(local2, local) and slam.dist.replay_sharded.local_maps is None
 
 
 def test_single_scan_owner_sweep_pass_threshold(slam):

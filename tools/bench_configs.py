@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Secondary measurements for the BASELINE.json configurations that are not the bench.py
-headline (configs[2] particles, configs[4] dense scan, long replays).  Prints one JSON line
-per configuration.  Not part of the driver contract; results are kept under profiles/."""
+"""Secondary measurements: the BASELINE.json configurations that are not the bench.py headline
+(configs[2] particles, configs[4] dense scan, the 5k-scan share of configs[3]) are run through
+`bench.py --config ...` and carry its in-run parity block against the C oracle (--no-check skips
+it); the scan-to-map observation (8f-1) and the drop-in call latencies are measured here.  Prints
+one JSON line per configuration.  Not part of the driver contract; results are kept under profiles/."""
 import argparse
 import importlib
 import json
@@ -27,72 +29,16 @@ def timed(fn, steps, warmup, torch):
     return (time.perf_counter() - t0) / steps
 
 
-def particles(slam, torch, P, steps, warmup, live=True):
-    """configs[2]: one 360-beam scan pair, P perturbed priors, one 400x400 @ 0.05 m map per
-    particle (maps persist across steps, as in a particle filter: no reset in the step)."""
-    A = slam._abi
-    dev = torch.device("cuda", 0)
-    ctx = A.Context(0, torch.cuda.current_stream(dev).cuda_stream)
-    rep = slam.synthetic.make_replay(2, 360, seed=2, stride=5)
-    n = 360
-    ct, st = A.trig_tables(AMIN, AMAX, n)
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    ranges2, cos_t, sin_t = d(rep.ranges.astype(np.float32)), d(ct), d(st)
-    prior = d(slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2)).reshape(P, 6))
-    pose_prev = d(np.zeros((P, 3)))
-    poses = torch.empty((P, 3), dtype=torch.float64, device=dev)
-    T = torch.empty((P, 9), dtype=torch.float64, device=dev)
-    iters = torch.empty(P, dtype=torch.int32, device=dev)
-    grid = slam.DeviceGrid.metric(P, 400, 400, 0.05, context=ctx)
-    # live pmap: every particle's ray cast owns its map, so it re-thresholds just its footprint
-    # and the 14.4 GB finalize pass over all maps disappears (finalize_dev on the live address
-    # is a no-op); --no-live measures the separate finalize pass
-    pmap = None if live else torch.empty((P, 400, 400), dtype=torch.int8, device=dev)
-    pmap_ptr = grid.live_pmap() if live else pmap.data_ptr()
-    L = A.lib()
-
-    def step():
-        A.check(L.slam_particles_dev(ctx.handle, ranges2.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), n, A.F64,
-                                     prior.data_ptr(), pose_prev.data_ptr(), P, 30, 1e-3, grid._h, None,
-                                     poses.data_ptr(), T.data_ptr(), iters.data_ptr()))
-        A.check(L.slam_grid_finalize_dev(ctx.handle, grid._h, pmap_ptr))
-
-    ctx.timing_enable(True)
-    dt = timed(step, steps, warmup, torch)
-    fam = ctx.timing_read()
-    ctx.check_status()
-    visits = grid.visits() / (steps + warmup)
-    return {"config": "configs[2]: %d particle hypotheses of one 360-beam scan pair, 400x400@0.05m map per particle%s"
-                      % (P, ", live pmap" if live else ", separate finalize pass"),
-            "value": P / dt, "unit": "particle-scans/s", "ms_per_step": dt * 1e3, "mean_iters": float(iters.float().mean()),
-            "cell_visits_per_step": visits,
-            "kernel_ms_per_step": {k: v[0] / v[1] for k, v in fam.items() if v[1]},
-            "finalize_GBps": (P * 160000 * 9 / (fam["finalize"][0] / fam["finalize"][1] * 1e-3) / 1e9) if fam.get("finalize", (0, 0))[1] else None,
-            "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
-
-
-def replay(slam, torch, scans, beams, grid_n, reso, room, points, steps, warmup, label, grid_group=0, grid_mode=1):
-    rep = slam.synthetic.make_replay(scans, beams, seed=3 if beams == 1080 else 1, room_scale=room, stride=5)
-    dr = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype=points)
-    dr.ctx.set_option("grid_group", grid_group)
-    dr.ctx.set_option("grid_mode", grid_mode)
-    grid = dr.make_grid(1, grid_n, grid_n, reso)
-    pmap = torch.empty((grid_n, grid_n), dtype=torch.int8, device=dr.dev)
-    A = slam._abi
-
-    def step():
-        dr.run(reset_grid=True)
-        A.check(A.lib().slam_grid_finalize_dev(dr.ctx.handle, grid._h, pmap.data_ptr()))
-
-    dr.ctx.timing_enable(True)
-    dt = timed(step, steps, warmup, torch)
-    fam = dr.ctx.timing_read()
-    _, _, iters = dr.results()
-    visits = grid.visits()
-    return {"config": label, "value": dr.scans_per_run / dt, "unit": "scans/s", "ms_per_step": dt * 1e3,
-            "mean_iters": float(iters.mean()), "cell_visits_per_step": visits,
-            "kernel_ms_per_step": {k: v[0] / v[1] for k, v in fam.items() if v[1]},
-            "grid_algorithmic_GBps": 9 * visits / (fam["grid"][0] / fam["grid"][1] * 1e-3) / 1e9}
+def via_bench(extra, check=True):
+    """The BASELINE.json configurations are bench.py --config modes (replay | particles | dense),
+    each with roofline, cpu_baseline and an in-run parity block against the C oracle; this runs
+    one of them as a child process and returns its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + list(extra)
+    if not check:
+        cmd.append("--no-parity")
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
 def mapobs(slam, torch, B, steps, warmup):
@@ -180,25 +126,24 @@ def main():
     ap.add_argument("--grid-mode", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-check", dest="check", action="store_false", help="skip the comparison with the oracle")
     args = ap.parse_args()
     import torch
     slam = importlib.import_module("a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd")
     for w in args.which.split(","):
         if w == "particles":
-            out = particles(slam, torch, args.particles, args.steps, args.warmup, live=True)
-        elif w == "particles_nolive":
-            out = particles(slam, torch, args.particles, args.steps, args.warmup, live=False)
+            out = via_bench(["--config", "particles", "--particles", str(args.particles), "--steps", str(args.steps),
+                             "--warmup", str(args.warmup)], args.check)
         elif w == "dropin":
             out = dropin(slam, torch, 200)
         elif w == "mapobs":
             out = mapobs(slam, torch, 4096, args.steps, args.warmup)
         elif w == "dense":
-            out = replay(slam, torch, 1000, 1080, 2000, 0.02, 2.0, "f16", args.steps, args.warmup,
-                         "configs[4]: 1k-scan replay, 1080 beams, 2000x2000@0.02m grid, f16 point buffers, room x2",
-                         grid_group=args.grid_group, grid_mode=args.grid_mode)
+            out = via_bench(["--config", "dense", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                             "--grid-group", str(args.grid_group), "--grid-mode", str(args.grid_mode)], args.check)
         elif w == "long":
-            out = replay(slam, torch, 5000, 360, 400, 0.05, 1.0, "f64", args.steps, args.warmup,
-                         "configs[3] per-GPU share: 5k-scan replay, 360 beams, 400x400@0.05m grid")
+            out = via_bench(["--config", "replay", "--scans", "5000", "--steps", str(args.steps), "--warmup", str(args.warmup)],
+                            args.check)
         else:
             continue
         print(json.dumps(out), flush=True)
