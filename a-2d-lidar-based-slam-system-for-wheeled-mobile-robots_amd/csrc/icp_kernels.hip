@@ -106,6 +106,74 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int 
     }
 }
 
+// Transposed wave reduction: N = 8 (or 4) values are summed over the wave's 64 lanes in 58 (33)
+// instructions instead of N x 23, by halving the number of live values at every exchange: at a
+// step whose partner differs in selection bit sigma, a lane KEEPS one value of each pair and sends
+// the other.  The exchanges are the DPP patterns of wave_sum_f64 (xor 1, xor 2, xor 7, xor 15
+// inside a row of 16 lanes), then the rows are added with v_permlane16_swap / v_permlane32_swap.
+// For a partner to hold the same value indices at every later step, the selection bits are
+// sigma1 = b0^b2, sigma2 = b1^b2, sigma3 = b2^b3 of the lane number: each flips under its own step's
+// xor mask and under none of the later ones.  Afterwards lane l holds the wave total of value
+// sigma1 + 2 sigma2 (+ 4 sigma3): lanes 0..3 hold values 0..3, lanes 7, 6, 5, 4 values 4..7.
+// Fixed order: deterministic, the same in every lane that holds the same value.
+struct LaneSel { bool s1, s2, s3; int idx8, idx4; };
+__device__ __forceinline__ LaneSel lane_sel(int lane)
+{
+    LaneSel s;
+    s.s1 = ((lane ^ (lane >> 2)) & 1) != 0;
+    s.s2 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+    s.s3 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0;
+    s.idx4 = (s.s1 ? 1 : 0) + (s.s2 ? 2 : 0);
+    s.idx8 = s.idx4 + (s.s3 ? 4 : 0);
+    return s;
+}
+template <int CTRL>
+__device__ __forceinline__ double tstep(double a, double b, bool sel)    // sel: keep b, send a
+{
+    const double keep = sel ? b : a, send = sel ? a : b;
+    return keep + dpp_xchg<CTRL>(send);
+}
+__device__ __forceinline__ double rows_sum_f64(double x)                 // x holds a 16-lane row total in every lane of the row
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
+    x = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);     // rows 0+1 | 2+3
+    lo = __double2loint(x); hi = __double2hiint(x);
+    a = __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]); // (0+1) + (2+3)
+}
+__device__ __forceinline__ double wave_reduce8(const double (&v)[8], const LaneSel &s)
+{
+    const double r0 = tstep<0xB1>(v[0], v[1], s.s1), r1 = tstep<0xB1>(v[2], v[3], s.s1);
+    const double r2 = tstep<0xB1>(v[4], v[5], s.s1), r3 = tstep<0xB1>(v[6], v[7], s.s1);
+    const double t0 = tstep<0x4E>(r0, r1, s.s2), t1 = tstep<0x4E>(r2, r3, s.s2);
+    double u = tstep<0x141>(t0, t1, s.s3);
+    u += dpp_xchg<0x140>(u);
+    return rows_sum_f64(u);
+}
+__device__ __forceinline__ double wave_reduce4(const double (&v)[4], const LaneSel &s)
+{
+    const double r0 = tstep<0xB1>(v[0], v[1], s.s1), r1 = tstep<0xB1>(v[2], v[3], s.s1);
+    double u = tstep<0x4E>(r0, r1, s.s2);
+    u += dpp_xchg<0x141>(u);
+    u += dpp_xchg<0x140>(u);
+    return rows_sum_f64(u);
+}
+// Workgroup total of the value this lane holds after wave_reduce8 / 4: lanes 0..7 of every wave
+// leave theirs in scratch[wave][value], and after the barrier every lane adds its value's column in
+// wave order.  `scratch` ([kMaxWaves][8]) alternates between two buffers on consecutive calls.
+__device__ __forceinline__ double block_total(double mine, int idx, double *scratch, int nwaves, int wave, int lane)
+{
+    if (nwaves == 1) return mine;
+    if (lane < 8) scratch[wave * 8 + idx] = mine;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nwaves; ++w) t += scratch[w * 8 + idx];
+    return t;
+}
+
 struct Rigid2 {
     double c, s, tx, ty;
 };
@@ -124,6 +192,22 @@ __device__ __forceinline__ Rigid2 kabsch_from_sums(double cax, double cay, doubl
     r.c = h == 0.0 ? 1.0 : A / h;           // W = 0: U.Vt of a zero matrix is the identity; NaN propagates
     r.s = h == 0.0 ? 0.0 : B / h;
     r.tx = cbx - (r.c * cax - r.s * cay);   // t = centroid_B - R.centroid_A (:172)
+    r.ty = cby - (r.s * cax + r.c * cay);
+    return r;
+}
+
+// The same with the two divisions done as ONE sequence (lane 0: A / h, lane 1: B / h) and broadcast:
+// identical bits, a dozen instructions fewer per iteration.  Needs all 64 lanes active.
+__device__ __forceinline__ Rigid2 kabsch_from_sums_wave(double cax, double cay, double cbx, double cby, double w00,
+                                                        double w01, double w10, double w11, int lane)
+{
+    const double A = w00 + w11, B = w10 - w01;
+    const double h = sqrt(A * A + B * B);
+    const double qd = ((lane & 1) ? B : A) / h;
+    Rigid2 r;
+    r.c = h == 0.0 ? 1.0 : readlane_f64(qd, 0);
+    r.s = h == 0.0 ? 0.0 : readlane_f64(qd, 1);
+    r.tx = cbx - (r.c * cax - r.s * cay);
     r.ty = cby - (r.s * cax + r.c * cay);
     return r;
 }
@@ -400,6 +484,7 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
 constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collapsed-set exchange (two parities)
+constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the reductions, two alternating buffers
 
 template <typename T, int QPT>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
@@ -409,10 +494,10 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
     Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
-    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][5][kMaxWaves]
-    unsigned *geo = reinterpret_cast<unsigned *>(red + 2 * 5 * kMaxWaves);                       // [4] polar_probe; geo[3]: source set collapsed
+    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][kMaxWaves][8]
+    unsigned *geo = reinterpret_cast<unsigned *>(red + kIcpRedDoubles);                          // [4] polar_probe; geo[3]: source set collapsed
     double *cref = reinterpret_cast<double *>(geo + 4);                                          // [2][4]: matched point of query 0, "all the same" flag
-    char *guard = smem + nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + kIcpExtraLds;
+    char *guard = smem + nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
     lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -480,6 +565,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     }
 
     const double dn = (double)n_src;
+    const LaneSel ls = lane_sel(lane);
     double pre_error = 0.0, mean_error = 0.0;
     int iters = 0, par = 0;
     for (int it = 0; it < a.max_iter; ++it) {
@@ -517,8 +603,16 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         par ^= 1;
         double *cr = cref + 4 * (it & 1);          // alternates per iteration: two barriers lie between a slot's reuse
         if (nwaves > 1 && tid == 0) { cr[0] = mx[0]; cr[1] = my[0]; cr[2] = 1.0; }   // (query 0 of thread 0 always exists)
-        block_sum<5>(v, red + par * 5 * kMaxWaves, nwaves, wave, lane);
-        double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;   // icp.py:154-155
+        // sums of the five quantities over the pair (transposed reduction: lane l ends up with the total
+        // of value idx8(l)), ONE division sequence for all of them, then five broadcasts
+        double cax, cay, cbx, cby;
+        {
+            const double v8[8] = {v[0], v[1], v[2], v[3], v[4], 0.0, 0.0, 0.0};
+            const double tot = block_total(wave_reduce8(v8, ls), ls.idx8, red + par * kMaxWaves * 8, nwaves, wave, lane);
+            const double qv = tot / dn;                              // icp.py:154-155, :75
+            cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
+            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7
+        }
         double w[4] = {0, 0, 0, 0};
         // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above
         const double m0x = nwaves > 1 ? cr[0] : readlane_f64(mx[0], 0), m0y = nwaves > 1 ? cr[1] : readlane_f64(my[0], 0);
@@ -533,10 +627,13 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         }
         if (nwaves > 1 && differs) cr[2] = 0.0;
         par ^= 1;
-        block_sum<4>(w, red + par * 5 * kMaxWaves, nwaves, wave, lane);
+        {
+            const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * kMaxWaves * 8, nwaves, wave, lane);
+            w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
+        }
         const bool tar_collapsed = nwaves > 1 ? cr[2] != 0.0 : !__any(differs);
         if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
-        Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);    // :69
+        Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {                              // src = T.src (:71)
             double nx = r.c * sx[q] + (-r.s) * sy[q] + r.tx;
@@ -544,7 +641,6 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             sx[q] = nx; sy[q] = ny;
         }
         ++iters;
-        mean_error = v[4] / dn;                                      // :75
         if (fabs(pre_error - mean_error) < a.tol) break;             // :76-77
         pre_error = mean_error;
     }
@@ -554,7 +650,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 #pragma unroll
     for (int q = 0; q < QPT; ++q)
         if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
-    block_sum<4>(v, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+    block_sum<4>(v, red + (par ^= 1) * kMaxWaves * 8, nwaves, wave, lane);
     double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
     double w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -564,7 +660,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
         }
     }
-    block_sum<4>(w, red + (par ^= 1) * 5 * kMaxWaves, nwaves, wave, lane);
+    block_sum<4>(w, red + (par ^= 1) * kMaxWaves * 8, nwaves, wave, lane);
     if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
     if (tid == 0) {
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
@@ -595,7 +691,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // (a handful of pairs cannot fill the chip anyway: one query per lane gives the lowest latency,
     // 0.13 instead of 0.15 ms for the drop-in ICP.process call)
     if (a.B > 64 && qpt < SLAM_ICP_QPT_PREF && a.n_src > 64 * SLAM_ICP_QPT_PREF) qpt = SLAM_ICP_QPT_PREF;   // queries per lane: fewer waves per pair, cheaper reductions (measured: 3 beats 2 by 3.5 % when replays overlap, 2 beats 1 by 8 % alone)
-    size_t lds = nn_lds_bytes(a.n_tar) + 2 * 5 * kMaxWaves * sizeof(double) + kIcpExtraLds + kLdsGuard;
+    size_t lds = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q)                                                                                        \
