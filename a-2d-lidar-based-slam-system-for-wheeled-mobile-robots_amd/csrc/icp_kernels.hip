@@ -685,12 +685,14 @@ template <typename T>
 static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 {
     int qpt = (a.n_src + 1023) / 1024;
-#ifndef SLAM_ICP_QPT_PREF
-#define SLAM_ICP_QPT_PREF 3
-#endif
-    // (a handful of pairs cannot fill the chip anyway: one query per lane gives the lowest latency,
-    // 0.13 instead of 0.15 ms for the drop-in ICP.process call)
-    if (a.B > 64 && qpt < SLAM_ICP_QPT_PREF && a.n_src > 64 * SLAM_ICP_QPT_PREF) qpt = SLAM_ICP_QPT_PREF;   // queries per lane: fewer waves per pair, cheaper reductions (measured: 3 beats 2 by 3.5 % when replays overlap, 2 beats 1 by 8 % alone)
+    // Queries per lane for batches (a handful of pairs cannot fill the chip anyway: one query per lane
+    // gives the lowest latency, 0.13 instead of 0.15 ms for the drop-in ICP.process call).  Fewer waves per
+    // pair repeat the per-iteration fixed work less often: three queries per lane are fastest when
+    // the chip is full (10 000 pairs: 0.510 against 0.536 ms; four overlapping 999-pair replays: 6.2
+    // against 6.0 M scans/s); a launch that cannot fill the chip on its own runs shorter with two
+    // (999 pairs alone: 0.134 against 0.163 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
+    int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
+    if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
     size_t lds = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);

@@ -82,6 +82,7 @@ struct slam_ctx {
     int64_t launches[SLAM_K_COUNT] = {0};
     int grid_mode = 1;    // 0: direct global atomics, 1: LDS window
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
+    int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
     // a second stream, so the map stage of one replay overlaps the scan matching of the next.
     int pipeline = 0;
@@ -414,6 +415,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     REQUIRE(name, "null name");
     if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "grid_mode is 0..3"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
+    else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
         REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
         TRY(join_from_grid(c));
@@ -593,7 +595,7 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     a.ppt = 0;
     a.B = B; a.n_tar = n_tar; a.n_src = n_src; a.max_iter = max_iter; a.tol = tol;
     a.T_out = T_out; a.iters_out = iters_out; a.err_out = mean_err_out;
-    a.status = c->status;
+    a.status = c->status; a.qpt_pref = c->icp_qpt;
     Timed t(c, SLAM_K_ICP);
     HIPCHK(launch_icp(a, dtype, c->stream));
     return SLAM_OK;
@@ -1055,7 +1057,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         a.ppt = n_scan - 1;
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
-        a.status = c->status;
+        a.status = c->status; a.qpt_pref = c->icp_qpt;
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }
@@ -1151,7 +1153,7 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         a.ppt = 0;
         a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
-        a.status = c->status;
+        a.status = c->status; a.qpt_pref = c->icp_qpt;
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }

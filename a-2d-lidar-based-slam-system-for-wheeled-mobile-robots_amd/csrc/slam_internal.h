@@ -81,6 +81,7 @@ struct IcpArgs {
     int32_t *iters_out;        // nullable [B]
     double *err_out;           // nullable [B]
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
+    int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
 };
 
 hipError_t launch_icp(const IcpArgs &a, int dtype, hipStream_t s);

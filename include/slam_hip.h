@@ -77,6 +77,9 @@ int slam_check_status(slam_ctx *ctx);
  *   or - for one shared map much larger than a window - walks recorded once and cast tile by
  *   tile; 0 = direct global atomics; 2 = tiles wherever they apply; 3 = always the window.
  * "grid_group": scans per workgroup / per tile group, 0 = automatic.
+ * "icp_qpt": queries per lane of batched scan matching, 1..3; 0 = by batch size (two for
+ *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
+ *   overlap several smaller launches set 3).
  * "pipeline": 1 = slam_replay_dev with a map runs as three stages on three streams of the
  *   context (scan matching | pose composition | slam_grid_reset -> ray cast ->
  *   slam_grid_finalize_dev), so the map stage of one replay overlaps the scan matching of the
