@@ -23,7 +23,7 @@ seeded synthetic inputs, and only the inputs and outputs are written out.
                           laserEstimation, calc_map_observation, the pose filter and the whole
                           Localization.laserCallback.
 
-Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,...,g8]
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only g1,...,g9]
 """
 from __future__ import annotations
 
@@ -687,14 +687,67 @@ def gen_g8(ref, out_dir):
          cloud=np.array(cloud_l), process_T_ref=np.array(Tp_l), process_iters_ref=np.array(it_l, dtype=np.int32))
 
 
+# ----------------------------------------------------------------------------
+# G9  nearest-neighbour ordering on sub-ulp near-ties
+# ----------------------------------------------------------------------------
+def gen_g9(ref, out_dir):
+    """W12m/icp.py:99-105 on constructed near-ties: pairs of target points whose squared distances
+    to the query differ by one unit in the last place (a) with ONE square root for both, (b) in
+    the fused square only (equal unfused squares), and (c) the failing case a property test found
+    (staircase ranges: symmetric neighbours).  Records which index the reference picks."""
+    from fractions import Fraction
+    import math
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def d2f(dx, dy):
+        return fma(dy, dy, dx * dx)
+    with quiet():
+        icp = ref.icp.ICP()
+    srcs, tars, picks, dists, kinds = [], [], [], [], []
+    rng = np.random.default_rng(3)
+    while len(srcs) < 6:                                             # (a) sqrt collapse
+        dx, dy = rng.uniform(0.5, 2.0, 2)
+        a, dx2 = d2f(dx, dy), dx
+        for _ in range(5):
+            dx2 = np.nextafter(dx2, 0.0)
+            b = d2f(dx2, dy)
+            if b == np.nextafter(a, 0.0) and math.sqrt(a) == math.sqrt(b):
+                srcs.append([0.0, 0.0]), tars.append([[dx, dy], [dx2, dy]]), kinds.append(0)
+                break
+    rng = np.random.default_rng(4)
+    while len(srcs) < 12:                                            # (b) fused squares differ, unfused equal
+        dx, dy = rng.uniform(0.5, 2.0, 2)
+        dx2 = dx
+        for _ in range(3):
+            dx2 = np.nextafter(dx2, 3.0)
+            if d2f(dx, dy) < d2f(dx2, dy) and dx * dx + dy * dy == dx2 * dx2 + dy * dy:
+                srcs.append([0.0, 0.0]), tars.append([[dx2, dy], [dx, dy]]), kinds.append(1)
+                break
+    for k in range(len(srcs)):
+        d, i = icp.findNearest(np.array([srcs[k]]), np.array(tars[k]))
+        picks.append(int(i[0])), dists.append(float(d[0]))
+    # (c) the whole clouds of the property test's example
+    rng = np.random.default_rng(196)
+    r = np.round(rng.uniform(0.5, 8.0, size=(2, 1)) + np.cumsum(rng.integers(-1, 2, size=(2, 54)), axis=1) * 0.25, 2).clip(0.25, 30).astype(np.float32)
+    ang = np.linspace(-1.5, 1.5, 54)
+    tar = np.stack([np.cos(ang) * r[0].astype(np.float64), np.sin(ang) * r[0].astype(np.float64)], axis=1)
+    src = np.stack([np.cos(ang) * r[1].astype(np.float64), np.sin(ang) * r[1].astype(np.float64)], axis=1)
+    d, i = icp.findNearest(src, tar)
+    save(out_dir, "g9_near_ties.npz", src=np.array(srcs), tar=np.array(tars), pick_ref=np.array(picks, dtype=np.int32),
+         dist_ref=np.array(dists), kind=np.array(kinds, dtype=np.int32), stair_ranges=r, stair_src=src, stair_tar=tar,
+         stair_idx_ref=i.astype(np.int32), stair_dist_ref=d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7,g8")
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6,g7,g8,g9")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference()
-    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6), ("g7", gen_g7), ("g8", gen_g8)):
+    for name, fn in (("g1", gen_g1), ("g2", gen_g2), ("g3", gen_g3), ("g4", gen_g4), ("g5", gen_g5), ("g6", gen_g6), ("g7", gen_g7), ("g8", gen_g8), ("g9", gen_g9)):
         if name in args.only.split(","):
             t0 = time.time()
             fn(ref, args.out)

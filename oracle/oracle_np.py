@@ -58,9 +58,9 @@ def find_nearest_loop(src, tar):
         min_dist = np.inf
         sx, sy = src[i, 0], src[i, 1]
         for j in range(tar.shape[0]):
-            dx = sx - tar[j, 0]
-            dy = sy - tar[j, 1]
-            dist = math.sqrt(dx * dx + dy * dy)  # np.linalg.norm of a 2-vector (:102)
+            # the reference's own expression (:102): sqrt(x.dot(x)), whose two-element dot is BLAS
+            # arithmetic - fma(x1, x1, x0*x0) in this container's NumPy, tests/test_nn_near_ties.py
+            dist = float(np.linalg.norm(np.array([sx - tar[j, 0], sy - tar[j, 1]])))
             if dist < min_dist:
                 min_dist = dist
                 indices[i] = j
@@ -73,13 +73,25 @@ def find_nearest(src, tar):
     i.e. the lowest j, matching the strict ``<`` of icp.py:103)."""
     dx = src[:, 0:1] - tar[None, :, 0]
     dy = src[:, 1:2] - tar[None, :, 1]
-    d = np.sqrt(dx * dx + dy * dy)
+    d = np.sqrt(dx * dx + dy * dy)            # unfused: the last place may differ from the reference's norm
     dd = np.where(np.isnan(d), np.inf, d)
     idx = np.argmin(dd, axis=1)
     dist = dd[np.arange(src.shape[0]), idx]
     never = ~np.isfinite(dist)  # inf < inf is False: nothing ever won
     idx = np.where(never, 0, idx)
     dist = np.where(never, 0.0, dist)
+    # candidates within a few units in the last place of the minimum are decided - and every
+    # distance is produced - by the reference's own expression, as find_nearest_loop does
+    close = dd <= (dist * (1.0 + 1e-14))[:, None]
+    for i in range(src.shape[0]):
+        if never[i]:
+            continue
+        best, bj = np.inf, 0
+        for j in np.nonzero(close[i])[0]:
+            dn = float(np.linalg.norm(np.array([src[i, 0] - tar[j, 0], src[i, 1] - tar[j, 1]])))
+            if dn < best:
+                best, bj = dn, j
+        idx[i], dist[i] = bj, best
     return dist, idx.astype(np.int64)
 
 

@@ -53,7 +53,11 @@ void orc_find_nearest(const double *sx, const double *sy, int n, const double *t
         for (int j = 0; j < m; ++j) {
             double dx = sx[i] - tx[j];
             double dy = sy[i] - ty[j];
-            double d = sqrt(dx * dx + dy * dy); /* np.linalg.norm of a 2-vector, :102 */
+            /* np.linalg.norm of a 2-vector (:102) is sqrt(x.dot(x)), and the two-element dot is BLAS
+             * arithmetic: fma(x1, x1, x0*x0) in the NumPy / OpenBLAS the golden vectors were made with
+             * (tests/test_nn_near_ties.py checks that it still is; the fused and the unfused square differ
+             * in the last place for a quarter of all inputs, which decides near-ties of symmetric clouds) */
+            double d = sqrt(fma(dy, dy, dx * dx));
             if (d < min_dist) {
                 min_dist = d;
                 idx[i] = j;

@@ -172,3 +172,68 @@ def test_scan_casting_all_paths_agree(slam, seed, n, S, mode, group, xw, scale, 
     assert np.array_equal(r["pmap"], np.where((p + h) > 0, np.where(occ, 100, 0), 50).astype(np.int8))
     g.close()
     ctx.close()
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 1100), xw=st.sampled_from([48, 208, 400, 640]),
+       yw=st.sampled_from([48, 208, 400, 640]), scale=st.sampled_from([5.0, 20.0, 50.0]), repeats=st.integers(1, 3),
+       shape=st.sampled_from(["uniform", "room", "far", "tiny"]))
+def test_single_scan_owner_kernel_random(slam, seed, n, xw, yw, scale, repeats, shape):
+    """One scan at a time into a map with a live pmap (the owner kernel: rows of 16 cells, up to
+    1024 beams, else the group kernel): random beam counts, map shapes, resolutions, origins in
+    and out of the map, ranges that stay inside / leave the map / vanish, repeated so that the
+    second pass meets non-zero counters and a pmap that is no longer 50."""
+    rng = np.random.default_rng(seed)
+    off_x, off_y = xw / (2 * scale), yw / (2 * scale)
+    ctx = slam.Context(0)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, context=ctx)
+    g.live_pmap()
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    for _ in range(repeats):
+        cx, cy = rng.uniform(-off_x * 1.2, off_x * 1.2), rng.uniform(-off_y * 1.2, off_y * 1.2)
+        ang = np.sort(rng.uniform(-np.pi, np.pi, n))
+        rmax = {"uniform": 1.5 * max(off_x, off_y), "room": 0.8 * min(off_x, off_y), "far": 4.0 * max(off_x, off_y), "tiny": 2.0 / scale}[shape]
+        d = rng.uniform(0, rmax, n)
+        if shape == "room":
+            d = np.minimum(d.max(), 0.6 * min(off_x, off_y) / np.maximum(np.abs(np.cos(ang)), np.abs(np.sin(ang))))
+        ox, oy = cx + np.cos(ang) * d, cy + np.sin(ang) * d
+        if seed % 4 == 0:
+            ox[: max(1, n // 5)] = np.inf                          # skipped beams
+        g.update_host(ox, oy, cx, cy)
+        og.update(ox, oy, cx, cy)
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
+        assert np.array_equal(r["pmap"], og.pmap) and g.visits() == og.visits
+    ctx.check_status()
+    g.close()
+    ctx.close()
+
+
+@settings(**{**SET, "max_examples": max(30, SET["max_examples"] // 2)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(2, 500), scans=st.integers(2, 6), points=st.sampled_from(["f64", "f32", "f16"]),
+       kind=st.sampled_from(["room", "noise", "steps", "mixed"]), span=st.sampled_from([6.28318, 4.712, 3.0, 1.0]))
+def test_replay_scan_matching_random_scans(slam, syn, seed, n, scans, points, kind, span):
+    """Scan matching of raw scans (targets that ARE scans: the beam-window search with the box
+    search behind it) on random scan streams: rooms, pure noise (no structure at all), staircase
+    ranges (exact ties between neighbouring beams), mixtures with inf and tiny ranges; any beam
+    count, angular span and point storage.  Iteration counts exact, transforms to 1e-9."""
+    from oracle import checks
+    rng = np.random.default_rng(seed)
+    amin, amax = -span / 2, span / 2
+    if kind == "room":
+        r = syn.make_replay(scans, n, seed=seed % 1000, stride=5).ranges.astype(np.float64)
+    elif kind == "noise":
+        r = rng.uniform(0.1, 20.0, size=(scans, n))
+    elif kind == "steps":
+        r = np.round(rng.uniform(0.5, 8.0, size=(scans, 1)) + np.cumsum(rng.integers(-1, 2, size=(scans, n)), axis=1) * 0.25, 2).clip(0.25, 30)
+    else:
+        r = syn.make_replay(scans, n, seed=seed % 1000, stride=5).ranges.astype(np.float64)
+        m = rng.uniform(size=r.shape)
+        r[m < 0.05] = np.inf
+        r[(m >= 0.05) & (m < 0.10)] = 0.1
+        r[(m >= 0.10) & (m < 0.15)] = rng.uniform(0.1, 30.0, size=int(((m >= 0.10) & (m < 0.15)).sum()))
+    r = r.astype(np.float32)
+    poses, T, it = slam.replay_host(r, amin, amax, dtype=points)
+    oposes, oT, oit, _ = checks.replay_reference(r, amin, amax, None, points, 30, 1e-3, threads=4)
+    assert np.array_equal(it, oit), (it, oit)
+    assert np.max(np.abs(T - oT.reshape(T.shape))) < 1e-8

@@ -1,28 +1,30 @@
-"""Nearest-neighbour ORDERING on sub-ulp near-ties: what the reference, the oracle and the
-kernel each pick, pinned so that the difference is documented instead of hidden.
+"""Nearest-neighbour ORDERING on sub-ulp near-ties: what the reference, the oracles and the
+kernels each pick, pinned so that the one remaining difference is documented instead of hidden.
 
 The reference orders candidates by ``np.linalg.norm(src[i] - tar[j])`` with strict '<' (W12m
-icp.py:102-103): sqrt(x.dot(x)).  The 2-element dot is BLAS arithmetic; in this container's
-NumPy / OpenBLAS it is fma(dy, dy, dx*dx) (checked below), on another build it may be the unfused
-dx*dx + dy*dy.  sqrt maps about half of all pairs of adjacent doubles to one value, so two
-candidates whose squared distances differ by one unit in the last place are a TIE for the
-reference (the lower index wins) while they are ordered for anything that compares squares.
+icp.py:102-103): sqrt(x.dot(x)).  The two-element dot is BLAS arithmetic; in this container's
+NumPy / OpenBLAS it is fma(x1, x1, x0*x0) (checked below - on another build it may be the
+unfused x0*x0 + x1*x1; the two differ in the last place for a quarter of all inputs, which
+decides near-ties of symmetric clouds: a property test found a staircase scan where the
+iteration count depends on it).  sqrt maps about half of all pairs of adjacent doubles to one
+value, so two candidates whose squares differ by one unit in the last place are usually a TIE
+for the reference (the lower index wins) while they are ordered for anything comparing squares.
 
-  kernel (nn_search / nn_polar / k_nn):  argmin of d2 = fma(dy, dy, dx*dx), lowest index among equal d2
-  C / NumPy oracle:                      argmin of sqrt(dx*dx + dy*dy) (unfused), lowest index among equals
-  reference here:                        argmin of sqrt(fma(dy, dy, dx*dx)), lowest index among equals
+  reference (golden vectors G9) and both oracles:  argmin of sqrt(fma(dy, dy, dx*dx)), lowest index among equals
+  kernels (nn_search / nn_polar / k_nn):           argmin of d2 = fma(dy, dy, dx*dx),  lowest index among equal d2
 
-They agree unless two candidates' squared distances differ by <= 2 ulp (probability ~1e-16 per
-comparison on real scans; exact ties - equal coordinates, quantised clouds - are unaffected:
-every rule then picks the lowest index).  The cases below are constructed to sit on that edge."""
+They agree unless two candidates' squares differ by 1-2 ulp AND share a square root (exact
+ties - equal coordinates, quantised or mirrored clouds - are unaffected: both rules then pick
+the lowest index).  G9 holds pairs constructed to sit on that edge, with the reference's picks."""
 import math
 from fractions import Fraction
 
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import load_golden, pkg
 from oracle import c_oracle as co
+from oracle import oracle_np as on
 
 
 def fma(a, b, c):
@@ -34,56 +36,20 @@ def d2_fused(dx, dy):
 
 
 def rule_kernel(src, tar):
-    d = [d2_fused(src[0] - t[0], src[1] - t[1]) for t in tar]
-    return int(np.argmin(d))                                      # first minimum
+    return int(np.argmin([d2_fused(src[0] - t[0], src[1] - t[1]) for t in tar]))          # first minimum of the fused squares
 
 
-def rule_oracle(src, tar):
-    d = [math.sqrt((src[0] - t[0]) * (src[0] - t[0]) + (src[1] - t[1]) * (src[1] - t[1])) for t in tar]
-    return int(np.argmin(d))
+def rule_reference(src, tar):
+    return int(np.argmin([math.sqrt(d2_fused(src[0] - t[0], src[1] - t[1])) for t in tar]))
 
 
-def rule_reference_here(src, tar):
-    best, idx = float("inf"), 0                                   # the reference's loop, icp.py:99-105
-    for j, t in enumerate(tar):
-        dist = np.linalg.norm(np.asarray(src) - np.asarray(t))
-        if dist < best:
-            best, idx = dist, j
-    return idx
-
-
-def sqrt_collapse_case():
-    """Two targets whose fused squared distances are adjacent doubles with ONE square root; the
-    lower index has the larger square."""
-    rng = np.random.default_rng(3)
-    while True:
-        dx, dy = rng.uniform(0.5, 2.0, 2)
-        a, dx2 = d2_fused(dx, dy), dx
-        for _ in range(5):
-            dx2 = np.nextafter(dx2, 0.0)
-            b = d2_fused(dx2, dy)
-            if b == np.nextafter(a, 0.0) and math.sqrt(a) == math.sqrt(b):
-                return (0.0, 0.0), [(float(dx), float(dy)), (float(dx2), float(dy))]
-
-
-def fused_order_case():
-    """Two targets whose UNFUSED squares are equal while the fused ones differ; the lower index
-    has the larger fused square."""
-    rng = np.random.default_rng(4)
-    while True:
-        dx, dy = rng.uniform(0.5, 2.0, 2)
-        dx2 = dx
-        for _ in range(3):
-            dx2 = np.nextafter(dx2, 3.0)
-            if d2_fused(dx, dy) < d2_fused(dx2, dy) and dx * dx + dy * dy == dx2 * dx2 + dy * dy:
-                return (0.0, 0.0), [(float(dx2), float(dy)), (float(dx), float(dy))]
-
-
-CASES = {"sqrt_collapse": sqrt_collapse_case, "fused_vs_unfused": fused_order_case}
+@pytest.fixture(scope="module")
+def g9():
+    return load_golden("g9_near_ties.npz")
 
 
 def test_numpy_dot_of_two_elements_is_fused_here():
-    """Premise of the table above: this container's x.dot(x) on 2 elements is fma(x1, x1, x0*x0)."""
+    """Premise of the oracles' distance: this container's x.dot(x) on 2 elements is fma(x1, x1, x0*x0)."""
     rng = np.random.default_rng(0)
     seen = 0
     for _ in range(20000):
@@ -95,43 +61,45 @@ def test_numpy_dot_of_two_elements_is_fused_here():
     assert seen > 1000
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
-def test_near_tie_rules_cpu(name):
-    src, tar = CASES[name]()
-    k, o, r = rule_kernel(src, tar), rule_oracle(src, tar), rule_reference_here(src, tar)
-    d, i = co.find_nearest(np.array([src]), np.array(tar))
-    assert int(i[0]) == o                                         # the C oracle follows its stated rule
-    if name == "sqrt_collapse":
-        # one square root for both: a tie for the reference and the oracle (index 0); the squares
-        # are ordered, so anything comparing squares picks index 1
-        assert (k, o, r) == (1, 0, 0)
-    else:
-        # equal unfused squares: a tie for the oracle (index 0); the fused squares differ by one ulp:
-        # the kernel picks index 1, the reference picks 1 unless their square roots collapse
-        assert (k, o) == (1, 0) and r in (0, 1)
-    # and with a third, clearly nearer, candidate every rule agrees again
-    tar3 = tar + [(tar[0][0] * 0.5, tar[0][1] * 0.5)]
-    assert rule_kernel(src, tar3) == rule_oracle(src, tar3) == rule_reference_here(src, tar3) == 2
+def test_oracles_follow_the_reference_on_near_ties(g9):
+    for k in range(len(g9["src"])):
+        src, tar = g9["src"][k], g9["tar"][k]
+        want = int(g9["pick_ref"][k])
+        assert rule_reference(src, tar) == want                   # the stated rule IS what the reference did
+        for d, i in (co.find_nearest(src[None], tar), on.find_nearest(src[None], tar), on.find_nearest_loop(src[None], tar)):
+            assert int(i[0]) == want and d[0] == g9["dist_ref"][k]
+        if g9["kind"][k] == 0:                                    # one square root for both: a tie, index 0
+            assert want == 0 and rule_kernel(src, tar) == 1       # ... while the squares are ordered
+    # the staircase scan of the property test: indices and distances of a whole 54 x 54 search, bit for bit
+    for fn in (co.find_nearest, on.find_nearest):
+        d, i = fn(g9["stair_src"], g9["stair_tar"])
+        assert np.array_equal(i, g9["stair_idx_ref"]) and np.array_equal(d, g9["stair_dist_ref"])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(CASES))
-def test_near_tie_rules_gpu(name):
-    """The device follows ITS stated rule (argmin of the fused square, lowest index among equal
-    squares) in all three searches: the stand-alone operator (k_nn), and - through ICP.process -
-    the box search; exact ties still go to the lowest index."""
+def test_kernels_order_by_the_fused_square(g9):
+    """The device follows ITS stated rule in the stand-alone operator and - through a whole scan
+    match - the beam-window and box searches; it equals the reference wherever the two rules agree
+    (everywhere except the constructed sqrt-collapse pairs), exact ties go to the lowest index."""
     slam = pkg()
-    src, tar = CASES[name]()
     icp = slam.ICP()
-    S, Tg = np.array([src]), np.array(tar)
-    d, i = icp.findNearest(S, Tg)
-    assert int(i[0]) == rule_kernel(src, tar) == 1
-    assert d[0] == math.sqrt(d2_fused(src[0] - tar[1][0], src[1] - tar[1][1]))
-    # exact tie (the same point twice): lowest index, as every rule says
-    d, i = icp.findNearest(S, np.array([tar[1], tar[1], tar[0]]))
-    assert int(i[0]) == 0
-    # padded to a block and more: the near-tied pair in the middle of a larger cloud
-    far = [(50.0 + k, 60.0) for k in range(40)]
-    cloud = np.array(far[:20] + tar + far[20:])
-    d, i = icp.findNearest(S, cloud)
-    assert int(i[0]) == 21
+    differ = 0
+    for k in range(len(g9["src"])):
+        src, tar = g9["src"][k], g9["tar"][k]
+        d, i = icp.findNearest(src[None], tar)
+        assert int(i[0]) == rule_kernel(src, tar) == 1
+        differ += int(i[0]) != int(g9["pick_ref"][k])
+        d, i = icp.findNearest(src[None], np.array([tar[1], tar[1], tar[0]]))     # exact tie: lowest index
+        assert int(i[0]) == 0
+        far = [(50.0 + j, 60.0) for j in range(40)]
+        d, i = icp.findNearest(src[None], np.array(far[:20] + [tuple(tar[0]), tuple(tar[1])] + far[20:]))
+        assert int(i[0]) == 21
+    assert differ == int(np.sum(g9["pick_ref"] == 0))             # the documented difference, nothing else
+    # the staircase scan: the kernel's search equals the reference's, indices and distances
+    d, i = icp.findNearest(g9["stair_src"], g9["stair_tar"])
+    assert np.array_equal(i, g9["stair_idx_ref"]) and np.array_equal(d, g9["stair_dist_ref"])
+    # ... and so does the whole scan match of those two scans through the beam-window search
+    r = g9["stair_ranges"]
+    poses, T, it = slam.replay_host(r, -1.5, 1.5)
+    oposes, oT, oit, _ = co.replay(r, -1.5, 1.5, None)
+    assert np.array_equal(it, oit) and np.max(np.abs(T - oT)) < 1e-9
