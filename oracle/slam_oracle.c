@@ -13,8 +13,9 @@
  * checks every function here against golden vectors produced by running the
  * reference's own Python (oracle/gen_golden.py -> tests/golden/).
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no fused multiply-add, so
- * the arithmetic is the plain IEEE double arithmetic CPython/NumPy perform).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: the compiler fuses nothing, so
+ * the arithmetic is the plain IEEE double arithmetic CPython/NumPy perform; the ONE
+ * fused multiply-add is written out, in orc_find_nearest, where the reference's BLAS dot has it).
  *
  * Point sets are structure-of-arrays (x[], y[]); the reference's 3xN matrices with a
  * row of ones (icp.py:42-49) carry no extra information.
