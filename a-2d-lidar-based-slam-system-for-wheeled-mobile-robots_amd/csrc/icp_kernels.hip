@@ -342,25 +342,36 @@ struct PolarGeo {
     float slack;      // angular slack of the stored points (radians)
 };
 
+template <int UNROLL>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n_tar, double sx, double sy, int seed,
                                          bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big)
 {
     seed = min(max(seed, 0), n_tar - 1);
-    const double2 ts = tarL[tslot(seed)];
-    const double U = dist2(sx, sy, ts.x, ts.y);
-    const float fsx = (float)sx, fsy = (float)sy, ftx = (float)ts.x, fty = (float)ts.y;
+    const float fsx = (float)sx, fsy = (float)sy;
     const float rs2 = fsx * fsx + fsy * fsy;
-    const float x2 = __fdividef((float)U * 1.000002f + 1e-30f, rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
-    const bool small = x2 < 0.25f;                                   // NaN: false
-    const float x = __fsqrt_rn(x2) * 1.000001f;
-    const float alpha = x * (1.0f + x2 * (0.16666667f + 0.1f * x2)) * 1.000002f + geo.slack;   // >= asin(x) for x < 0.5
-    const float y = __fdividef(ftx * fsy - fty * fsx, ftx * fsx + fty * fsy);       // tan(delta), |delta| <= 30 degrees
-    const float y3 = y * y * y * 0.33333334f;
-    const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;              // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
-    const float dlo = (y >= 0.0f ? y - y3 : y) - 4e-6f;
-    const int lo = seed + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db)) - 1;
-    const int hi = seed + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db)) + 1;
-    big = active && !(small && hi - lo < kPolarMax);
+    int lo, hi;
+    // the window of beam indices around beam j that holds every target closer than t_j; false: no usable window
+    auto window = [&](int j, int &wlo, int &whi) -> bool {
+        const double2 ts = tarL[tslot(j)];
+        const double U = dist2(sx, sy, ts.x, ts.y);
+        const float ftx = (float)ts.x, fty = (float)ts.y;
+        const float x2 = __fdividef((float)U * 1.000002f + 1e-30f, rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
+        const bool small = x2 < 0.25f;                               // NaN: false
+        const float x = __fsqrt_rn(x2) * 1.000001f;
+        const float alpha = x * (1.0f + x2 * (0.16666667f + 0.1f * x2)) * 1.000002f + geo.slack;   // >= asin(x) for x < 0.5
+        const float y = __fdividef(ftx * fsy - fty * fsx, ftx * fsx + fty * fsy);       // tan(delta), |delta| <= 30 degrees
+        const float y3 = y * y * y * 0.33333334f;
+        const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;          // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
+        const float dlo = (y >= 0.0f ? y - y3 : y) - 4e-6f;
+        wlo = j + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db)) - 1;
+        whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db)) + 1;
+        return small && whi - wlo < kPolarMax;
+    };
+    const bool fits = window(seed, lo, hi);
+    // (tried: a second window around the beam that points at the query for lanes whose first one is
+    // too wide.  It never helps: the first iteration's guess IS that beam - source and target points of
+    // one index lie on one ray - and its 14 % wide lanes see a different surface than the target did)
+    big = active && !fits;
     const bool go = active && !big;
     // three index ranges in ascending order: wrapped from above | the window | wrapped from below
     const int m0 = max(lo, 0), m1 = min(hi, n_tar - 1);
@@ -369,7 +380,32 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n
     double best = INFINITY;
     int bj = 0;
     auto scan = [&](int a0, int a1) {
-        for (int k = a0; __any(k <= a1); k += 2) {
+        // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
+        // the chip is bound by the LATENCY of a trip (read, distance, compare chain, wave-wide loop
+        // test): 999 pairs alone 0.121 against 0.125 ms; a full chip is bound by issue and the rounding
+        // of the windows to whole trips costs more than the shorter chain saves (10 000 pairs: 0.468
+        // against 0.456 ms), so those launches take two per trip.
+        if (UNROLL == 4) for (int k = a0; __any(k <= a1); k += 4) {
+            if (k <= a1) {
+                const int k1 = min(k + 1, a1), k2 = min(k + 2, a1), k3 = min(k + 3, a1);   // (a repeated candidate cannot win: strict '<')
+                const double2 t0 = tarL[tslot(k)], t1 = tarL[tslot(k1)], t2 = tarL[tslot(k2)], t3 = tarL[tslot(k3)];
+                const double d0 = dist2(sx, sy, t0.x, t0.y), d1 = dist2(sx, sy, t1.x, t1.y);
+                const double d2 = dist2(sx, sy, t2.x, t2.y), d3 = dist2(sx, sy, t3.x, t3.y);
+                bool c = d0 < best;
+                best = fmin(best, d0);                               // NaN never lowers it
+                bj = c ? k : bj;
+                c = d1 < best;
+                best = fmin(best, d1);
+                bj = c ? k1 : bj;
+                c = d2 < best;
+                best = fmin(best, d2);
+                bj = c ? k2 : bj;
+                c = d3 < best;
+                best = fmin(best, d3);
+                bj = c ? k3 : bj;
+            }
+        }
+        else for (int k = a0; __any(k <= a1); k += 2) {
             if (k <= a1) {
                 const double2 t0 = tarL[tslot(k)];
                 const int k1 = min(k + 1, a1);                       // (a repeated candidate cannot win: strict '<')
@@ -431,6 +467,12 @@ struct Cloud {
 template <typename T>
 __device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsigned *geo)
 {
+    // per-lane partials, one butterfly per wave, one LDS atomic per wave and word (an atomic per
+    // beam is turned by the compiler into a serial loop over the 64 lanes: 12 % of a pair's
+    // set-up time when it was written that way)
+    unsigned mn = 0x7f800000u;
+    float sum = 0.0f;
+    bool bad = false;
     for (int j = threadIdx.x; j < n_tar; j += blockDim.x) {
         const double c0 = tar.cos_t[j], s0 = tar.sin_t[j];
         bool ok = fabs(c0 * c0 + s0 * s0 - 1.0) < 1e-6 && !(tar.ranges[j] < 0.0f);
@@ -439,22 +481,36 @@ __device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsi
             const double cr = c0 * s1 - s0 * c1, dt = c0 * c1 + s0 * s1;
             ok = ok && cr > 0.0 && cr <= 0.5 && dt > 0.0;
             if (ok) {
-                atomicMin(&geo[0], __float_as_uint((float)cr * 0.999999f));
-                atomicAdd(reinterpret_cast<float *>(&geo[2]), (float)(cr * (1.0 + cr * cr * (1.0 / 6.0 + 0.1 * cr * cr))) * 1.000001f);
+                mn = min(mn, __float_as_uint((float)cr * 0.999999f));
+                sum += (float)(cr * (1.0 + cr * cr * (1.0 / 6.0 + 0.1 * cr * cr))) * 1.000001f;
             }
         }
-        if (!ok) geo[1] = 0u;
+        bad |= !ok;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, off));
+        sum += __shfl_xor(sum, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&geo[0], mn);
+        atomicAdd(reinterpret_cast<float *>(&geo[2]), sum * 1.00001f);       // (the order of the additions is not fixed: pad)
+    }
+    if (bad) geo[1] = 0u;
 }
 
 template <typename T>
-__device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, double2 *tarL, Box *boxes, Box *boxes4)
+__device__ __forceinline__ void stage_points(const Cloud<T> &tar, int n_tar, double2 *tarL)
 {
     const int nb = nn_blocks(n_tar), npad = nb * kNNBlock;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     for (int j = threadIdx.x; j < npad; j += blockDim.x)
         tarL[tslot(j)] = j < n_tar ? tar.at(j) : make_double2(qnan, qnan);
-    __syncthreads();
+}
+
+__device__ __forceinline__ void stage_boxes(int n_tar, const double2 *tarL, Box *boxes, Box *boxes4)
+{
+    const int nb = nn_blocks(n_tar);
     for (int b = threadIdx.x; b < nn_boxes_padded(n_tar); b += blockDim.x) {
         Box bx{INFINITY, -INFINITY, INFINITY, -INFINITY};            // stays empty for the padding boxes
         if (b < nb) {
@@ -480,15 +536,87 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, double2 *tarL, Box *boxes, Box *boxes4)
+{
+    stage_points(tar, n_tar, tarL);
+    __syncthreads();
+    stage_boxes(n_tar, tarL, boxes, boxes4);
+}
+
 // ---------------------------------------------------------------------------------
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
 constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collapsed-set exchange (two parities)
 constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the reductions, two alternating buffers
 
-template <typename T, int QPT>
-__global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
+// Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles
+// of each phase to the 64-bit counters behind the status word (slam_debug_read): [0] staging, [1]
+// search, [2] centroid reduction, [3] products + reduction, [4] Kabsch + transform, [5] final T;
+// [6..9]: phases 1..4 of the FIRST iteration (the others hold iterations >= 1), [10] iterations, [11] pairs, [12] lifetimes,
+// [13] lifetimes on the 100 MHz clock, [14] 2^62 - earliest start, [15] latest end (100 MHz clock).
+#ifdef SLAM_STAMPS_ICP
+#define ISTAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0, st_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_big[4] = {0, 0, 0, 0}, st_real = __builtin_amdgcn_s_memrealtime()
+#define ISTAMP(k)                                                                                        \
+    do {                                                                                                 \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+        st_acc[k] += t_ - st_t0;                                                                         \
+        st_t0 = t_;                                                                                      \
+    } while (0)
+#if SLAM_STAMPS_ICP == 2   /* when do pairs start and end?  [0..11], [12..23]: histograms in 15 us buckets from the first start; [24]: that start */
+#define ISTAMP_END(iters)                                                                                \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
+            unsigned long long base_ = atomicCAS(c_ + 24, 0ull, st_real);                                \
+            if (base_ == 0ull) base_ = st_real;                                                          \
+            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
+            long long s0_ = (long long)(st_real - base_) / 1500, s1_ = (long long)(r_ - base_) / 1500;   \
+            atomicAdd(c_ + min(max(s0_, 0ll), 11ll), 1ull);                                              \
+            atomicAdd(c_ + 12 + min(max(s1_, 0ll), 11ll), 1ull);                                         \
+        }                                                                                                \
+    } while (0)
+#define ISTAMP_BIG(it, big)
+#else
+#define ISTAMP_BIG(it, big)                                                                              \
+    do {                                                                                                 \
+        st_big[(it) == 0 ? 0 : 2] += __popcll(__ballot(big));                                            \
+        st_big[(it) == 0 ? 1 : 3] += __any(big) ? 1 : 0;                                                 \
+    } while (0)
+#define ISTAMP_END(iters)                                                                                \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0)                                                                     \
+            for (int k_ = 0; k_ < 4; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(a.status + 8) + 21 + k_, st_big[k_]); \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
+            for (int k_ = 0; k_ < 10; ++k_) atomicAdd(c_ + k_, st_acc[k_]);                              \
+            for (int k_ = 0; k_ < 5; ++k_) atomicAdd(c_ + 16 + k_, st_acc[10 + k_]);                      \
+            atomicAdd(c_ + 10, (unsigned long long)(iters));                                             \
+            atomicAdd(c_ + 11, 1ull);                                                                    \
+            atomicAdd(c_ + 12, __builtin_amdgcn_s_memtime() - st_first);                                 \
+            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
+            atomicAdd(c_ + 13, r_ - st_real);                                                            \
+            atomicMax(c_ + 14, (1ull << 62) - st_real);                                                  \
+            atomicMax(c_ + 15, r_);                                                                      \
+        }                                                                                                \
+    } while (0)
+#endif
+#else
+#define ISTAMP_DECL
+#define ISTAMP(k)
+#define ISTAMP_BIG(it, big)
+#define ISTAMP_END(iters)
+#endif
+
+#ifdef SLAM_ICP_SGPR
+#define SLAM_ICP_ATTR __attribute__((amdgpu_num_sgpr(SLAM_ICP_SGPR)))
+#else
+#define SLAM_ICP_ATTR
+#endif
+template <typename T, int QPT, int UNROLL>
+__global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
 {
+    ISTAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblocks = nn_blocks(a.n_tar);
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
@@ -514,10 +642,15 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     }
 
     if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; }
-    stage_target(tar, n_tar, tarL, boxes, boxes4);                   // (barriers inside: geo is initialised for the probe)
+    stage_points(tar, n_tar, tarL);
+    __syncthreads();                                                 // (geo is initialised for the probe)
+    ISTAMP(10);
+    stage_boxes(n_tar, tarL, boxes, boxes4);
+    ISTAMP(11);
 #ifndef SLAM_NO_POLAR
     if (a.ranges) polar_probe(tar, n_tar, geo);
 #endif
+    ISTAMP(12);
 
     double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
     int seed[QPT];
@@ -538,6 +671,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         sy[q] = ay[q] = y;
         seed[q] = i;                             // first guess: the same beam index
     }
+    ISTAMP(13);
     {
         // Collapsed sets (every point of a set is ONE point): W = BB^T.AA is mathematically zero and
         // the canonical answer is R = I (the SVD of a zero matrix), t = centroid_B - centroid_A.  The
@@ -566,6 +700,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 
     const double dn = (double)n_src;
     const LaneSel ls = lane_sel(lane);
+    ISTAMP(14);
     double pre_error = 0.0, mean_error = 0.0;
     int iters = 0, par = 0;
     for (int it = 0; it < a.max_iter; ++it) {
@@ -576,12 +711,13 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             double d2; int j;
             if (pg.inv_db > 0.0f) {                                  // wave-uniform: the target is a scan
                 bool big;
-                nn_polar(tarL, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
+                nn_polar<UNROLL>(tarL, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
                 // The few queries without a good match (newly visible surfaces; they come in runs of
                 // neighbouring beams: measured 1.3 % of the queries, in 10 % of the wave-queries, 8 lanes at
                 // a time) take the box search.  Tried and dropped: scanning the whole cloud for them
                 // with the wave, one query after the other (4.37e7 instead of 4.00e7 instructions per
                 // launch), and searching a lane's queries together in one wave-wide loop (4.55e7).
+                ISTAMP_BIG(it, big);
                 if (__any(big)) {
                     double d2b; int jb;
                     nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, big, d2b, jb);
@@ -600,6 +736,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         // Two passes, as the reference (centroids, then centred products, icp.py:154-160): when
         // every source point matches the same target the centred products are exactly zero and
         // R falls back to the identity, which one-pass raw moments would turn into rounding noise.
+        ISTAMP(it == 0 ? 6 : 1);
         par ^= 1;
         double *cr = cref + 4 * (it & 1);          // alternates per iteration: two barriers lie between a slot's reuse
         if (nwaves > 1 && tid == 0) { cr[0] = mx[0]; cr[1] = my[0]; cr[2] = 1.0; }   // (query 0 of thread 0 always exists)
@@ -613,6 +750,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
             mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7
         }
+        ISTAMP(it == 0 ? 7 : 2);
         double w[4] = {0, 0, 0, 0};
         // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above
         const double m0x = nwaves > 1 ? cr[0] : readlane_f64(mx[0], 0), m0y = nwaves > 1 ? cr[1] : readlane_f64(my[0], 0);
@@ -631,6 +769,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * kMaxWaves * 8, nwaves, wave, lane);
             w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
         }
+        ISTAMP(it == 0 ? 8 : 3);
         const bool tar_collapsed = nwaves > 1 ? cr[2] != 0.0 : !__any(differs);
         if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
         Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
@@ -641,6 +780,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             sx[q] = nx; sy[q] = ny;
         }
         ++iters;
+        ISTAMP(it == 0 ? 9 : 4);
         if (fabs(pre_error - mean_error) < a.tol) break;             // :76-77
         pre_error = mean_error;
     }
@@ -671,6 +811,8 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         if (a.iters_out) a.iters_out[b] = iters;
         if (a.err_out) a.err_out[b] = mean_error;
     }
+    ISTAMP(5);
+    ISTAMP_END(iters);
     lds_guard_check(guard, a.status);
 }
 
@@ -690,29 +832,33 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // pair repeat the per-iteration fixed work less often: three queries per lane are fastest when
     // the chip is full (10 000 pairs: 0.510 against 0.536 ms; four overlapping 999-pair replays: 6.2
     // against 6.0 M scans/s); a launch that cannot fill the chip on its own runs shorter with two
-    // (999 pairs alone: 0.134 against 0.163 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
+    // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
     int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
     if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
     size_t lds = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
+#ifdef SLAM_ICP_LDS_PAD
+    if (a.B > 64) lds += SLAM_ICP_LDS_PAD;      // tuning experiments: fewer resident workgroups per CU
+#endif
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
-#define SLAM_ICP_CASE(Q)                                                                                        \
+#define SLAM_ICP_CASE(Q, U)                                                                                     \
     {                                                                                                           \
         if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q>),                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                        \
+        SLAM_LAUNCH((k_icp<T, Q, U>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                     \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid
     // once per pair - was measured: 12 % fewer instructions, but 0.28 instead of 0.20 ms alone and
     // no faster with replays overlapping: dropped)
-    if (qpt <= 1) SLAM_ICP_CASE(1)
-    else if (qpt <= 2) SLAM_ICP_CASE(2)
-    else if (qpt <= 3) SLAM_ICP_CASE(3)
-    else if (qpt <= 4) SLAM_ICP_CASE(4)
-    else if (qpt <= 8) SLAM_ICP_CASE(8)
+    // (candidates per trip of the beam-window search: see nn_polar - four where latency counts, two where issue does)
+    if (qpt <= 1) SLAM_ICP_CASE(1, 4)
+    else if (qpt <= 2) SLAM_ICP_CASE(2, 4)
+    else if (qpt <= 3) SLAM_ICP_CASE(3, 2)
+    else if (qpt <= 4) SLAM_ICP_CASE(4, 2)
+    else if (qpt <= 8) SLAM_ICP_CASE(8, 2)
     else return hipErrorInvalidValue;   // n_src > 8192
 #undef SLAM_ICP_CASE
     return hipGetLastError();

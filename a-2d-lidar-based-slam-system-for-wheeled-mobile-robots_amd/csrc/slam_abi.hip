@@ -469,7 +469,7 @@ int slam_timing_read(slam_ctx *c, double ms_out[SLAM_K_COUNT], int64_t launches_
     return SLAM_OK;
 }
 
-#ifdef SLAM_STAMPS
+#if defined(SLAM_STAMPS) || defined(SLAM_STAMPS_ICP)
 /* diagnostic builds only: the 256-byte status block (word 0: status bits; from word 8: phase counters) */
 int slam_debug_read(slam_ctx *c, void *out256, int clear)
 {

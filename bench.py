@@ -233,7 +233,7 @@ class ReplayWorkload:
             ln.dr.ctx.set_option("pipeline", args.pipeline)
             # several replays share the chip: three queries per lane (fewest instructions); a lone
             # replay leaves the choice to the library (two: shortest launch)
-            ln.dr.ctx.set_option("icp_qpt", 3 if n_lanes > 1 else 0)
+            ln.dr.ctx.set_option("icp_qpt", int(os.environ.get("SLAM_BENCH_QPT", 3 if n_lanes > 1 else 0)))
             ln.count = 0
             self.lanes.append(ln)
         self.dev = self.lanes[0].dr.dev
