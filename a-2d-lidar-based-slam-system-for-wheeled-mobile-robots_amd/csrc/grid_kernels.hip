@@ -497,11 +497,12 @@ __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src 
     return nvis;
 }
 
+constexpr int kWinBoxInts = 48;        // bbox[4], window[4], flags; from [16]: the two direction halves (see k_grid_update_win)
 __host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)group * sizeof(ScanConst) + 15) & ~(size_t)15; }
 __host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
 __host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap, int win_cells)
 {
-    return win_sc_bytes(group) + 64 + kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)win_cells * 2 + kLdsGuard;
+    return win_sc_bytes(group) + kWinBoxInts * 4 + 2 * kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)win_cells * 2 + kLdsGuard;
 }
 // Window capacity (16-bit cells) of a launch: kWinCells, or, for small groups, whatever still lets two
 // workgroups share a CU's 160 KiB (a single 360-beam scan: 40 288 cells instead of 36 864 - the
@@ -523,8 +524,8 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // second workgroup on the CU
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [group_size]
     int *box = reinterpret_cast<int *>(smem + win_sc_bytes(group_size));                  // bbox[4], window[4], flags
-    int *hist = box + 16;                                                                 // [kSortBins]
-    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);         // [sort_cap]
+    int *hist = box + kWinBoxInts;                                                        // [2][kSortBins]
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + 2 * kSortBins);     // [sort_cap]
     unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);                       // [W][Hp/2] dwords
     char *guard = reinterpret_cast<char *>(win) + (size_t)win_cells * 2;
     lds_guard_fill(guard);
@@ -541,31 +542,53 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // exclusive owner of the map + live pmap + rows that are a multiple of 4 cells: the flush is a
     // plain vectorised read-modify-write of the touched rectangle that also re-thresholds pmap
     const bool fused = exclusive && g.pmap_live && (g.yw & 3) == 0 && (((size_t)gi * g.xw * g.yw) & 3) == 0;
+    // rows of an even number of cells: two neighbouring counters are one aligned 8-byte word, and the two
+    // 16-bit counts of a window dword are flushed by ONE 64-bit atomic (see the flush)
+    const bool pair64 = (g.yw & 1) == 0 && (((size_t)gi * g.xw * g.yw) & 1) == 0;
     if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
     unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
-    if (tid == 0) { box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; box[15] = INT_MAX; }
+    if (tid == 0) {
+        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; box[15] = INT_MAX;
+        box[16] = box[17] = box[20] = box[21] = INT_MAX; box[18] = box[19] = box[22] = box[23] = INT_MIN;
+        box[34] = 1; box[35] = 0;
+    }
     const bool sorted = nrays <= sort_cap;
+    // Direction halves (DESIGN.md "K4 halves"): a ray never crosses the column of its origin, so the
+    // rays that run towards larger x and those that run towards smaller x touch two disjoint halves of
+    // the group's bounding box (up to the few columns the origins of the group's scans differ by).
+    // When the whole box does not fit the window - a 10 m x 8 m room seen at an angle spans 250 x 250
+    // cells, 1.5 windows - each half gets the window to itself, one after the other: every ray is still
+    // walked once, and none of its cells takes the scattered-global-atomic path (40 % of the walk before).
+    const bool halves_ok = sorted && !exclusive;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
-    if (tid < kSortBins) hist[tid] = 0;
+    for (int k = tid; k < 2 * kSortBins; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     STAMP(0);                                   // scan constants
 
     // pass 1: bounding box of everything the group's rays can touch
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
+    int hb[2][4] = {{INT_MAX, INT_MAX, INT_MIN, INT_MIN}, {INT_MAX, INT_MAX, INT_MIN, INT_MIN}};   // boxes of the two halves
     for (int r = tid; r < nrays; r += blockDim.x) {
-        int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0;
+        int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0, side = 0;
         if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) {
-            bx0 = min(bx0, min(pox, sc[s].pcx)); bx1 = max(bx1, max(pox, sc[s].pcx));
-            by0 = min(by0, min(poy, sc[s].pcy)); by1 = max(by1, max(poy, sc[s].pcy));
+            const int rx0 = min(pox, sc[s].pcx), rx1 = max(pox, sc[s].pcx), ry0 = min(poy, sc[s].pcy), ry1 = max(poy, sc[s].pcy);
+            bx0 = min(bx0, rx0); bx1 = max(bx1, rx1);
+            by0 = min(by0, ry0); by1 = max(by1, ry1);
             len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
+            side = pox >= sc[s].pcx ? 1 : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                hb[h][0] = side == h ? min(hb[h][0], rx0) : hb[h][0]; hb[h][1] = side == h ? min(hb[h][1], ry0) : hb[h][1];
+                hb[h][2] = side == h ? max(hb[h][2], rx1) : hb[h][2]; hb[h][3] = side == h ? max(hb[h][3], ry1) : hb[h][3];
+            }
         }
         // a single scan stops at its first beam that Python's int() would raise on (mapping.py:29-36:
         // the beams before it have been applied when the exception leaves update(), and the error is
         // that beam's); a group of scans reports any bad beam and casts all the others
         if (cnt == 1) { if (b2) atomicMin(&box[15], i); }
         else bad |= b2;
-        if (sorted) {                                                // bin by length, longest first
-            int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);
+        if (sorted) {                                                // bin by (half,) length, longest first
+            int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1) + (halves_ok ? side * kSortBins : 0);
             bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
             atomicAdd(&hist[bin], 1);
         }
@@ -573,6 +596,15 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
     if (lane == 0 && bx0 <= bx1) {
         atomicMin(&box[0], bx0); atomicMin(&box[1], by0); atomicMax(&box[2], bx1); atomicMax(&box[3], by1);
+    }
+    if (halves_ok) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int a0 = wave_min_i32(hb[h][0]), a1 = wave_min_i32(hb[h][1]), a2 = wave_max_i32(hb[h][2]), a3 = wave_max_i32(hb[h][3]);
+            if (lane == 0 && a0 <= a2) {
+                atomicMin(&box[16 + 4 * h], a0); atomicMin(&box[17 + 4 * h], a1); atomicMax(&box[18 + 4 * h], a2); atomicMax(&box[19 + 4 * h], a3);
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -596,11 +628,13 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
 #endif
             if (fused) y0 &= ~3;                                      // quads of the fused flush line up with the window's dwords
+            else if (pair64) y0 &= ~1;                                // the window's dwords line up with 8-byte pairs of counters
             W = x1 - x0 + 1; H = y1 - y0 + 1;
             if (!fastwin && (long)W * ((H + 1) & ~1) > win_cells) {   // keep a sub-rectangle around the first origin
                 int Hd = min(H, 192), Wd = min(W, win_cells / ((Hd + 1) & ~1));   // rows are stored padded to an even height
                 int cx0 = min(max(sc[0].pcx - Wd / 2, x0), x1 - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, y0), y1 - Hd + 1);
                 if (fused) cy0 &= ~3;
+                else if (pair64) cy0 &= ~1;
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
                 covers = 0;
             }
@@ -615,22 +649,55 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
         }
         box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers; box[10] = fastwin; box[11] = strip_w;
+#ifndef SLAM_NO_HALVES
+        if (halves_ok && !covers && !fastwin && W > 0) {
+            // the whole box does not fit: one window per direction half.  A half that is still too large keeps
+            // the sub-rectangle next to the origin column (its rays start there) and leaves the rest to the
+            // direct atomics, as the whole box did.
+            bool any = false;
+            for (int h = 0; h < 2; ++h) {
+                int hx0 = max(box[16 + 4 * h], 0), hy0 = max(box[17 + 4 * h], 0), hx1 = min(box[18 + 4 * h], g.xw - 1), hy1 = min(box[19 + 4 * h], g.yw - 1);
+                int hW = 0, hH = 0, hc = 1;
+                if (hx0 <= hx1 && hy0 <= hy1) {
+                    if (pair64) hy0 &= ~1;
+                    hW = hx1 - hx0 + 1; hH = hy1 - hy0 + 1;
+                    if ((long)hW * ((hH + 1) & ~1) > win_cells) {
+                        int Hd = min(hH, 192), Wd = min(hW, win_cells / ((Hd + 1) & ~1));
+                        int cx0 = h ? hx0 : hx1 - Wd + 1, cy0 = min(max(sc[0].pcy - Hd / 2, hy0), hy1 - Hd + 1);
+                        if (pair64) cy0 &= ~1;
+                        hx0 = cx0; hy0 = cy0; hW = Wd; hH = Hd; hc = 0;
+                    }
+                    if ((long)hW * ((hH + 1) >> 1) > win_cells / 2) { atomicOr(g.status, kStatusGuard); hW = 0; hH = 0; hc = 0; }
+                    any = true;
+                }
+                int *o = h ? box + 24 : box + 4;
+                o[0] = hx0; o[1] = hy0; o[2] = hW; o[3] = hH; o[4] = hc;
+            }
+            if (any) box[34] = 2;
+        }
+#endif
     }
     __syncthreads();
     STAMP(1);                                   // pass 1: endpoints, bounding box, histogram
-    const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
-    const bool covers = box[8] != 0;      // the window holds every in-map cell the group can touch
-    const int Hp2 = (H + 1) >> 1;         // dwords per window row
+    int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
+    bool covers = box[8] != 0;            // the window holds every in-map cell the group can touch
+    int Hp2 = (H + 1) >> 1;               // dwords per window row
+    const int phases = box[34];           // 2: one window per direction half
     if (sorted) {
-        // counting sort of the ray ids by length bin: exclusive scan of the histogram (wave 0),
+        // counting sort of the ray ids by (half,) length bin: exclusive scan of the histogram (wave 0),
         // then every ray claims a slot in its bin.  Order inside a bin is arbitrary; the map
         // update does not depend on ray order.
         if (wave == 0) {
-            int a = hist[2 * lane], b2 = hist[2 * lane + 1], tot = a + b2, inc = tot;
+            int h4[4], tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { h4[u] = hist[4 * lane + u]; tot += h4[u]; }
+            int inc = tot;
 #pragma unroll
             for (int off = 1; off < kWave; off <<= 1) { int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
-            hist[2 * lane] = inc - tot;
-            hist[2 * lane + 1] = inc - tot + a;
+            int run = inc - tot;
+            if (lane == kSortBins / 4) box[35] = run;                // rays of half 0 (all of them without halves: unused)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { hist[4 * lane + u] = run; run += h4[u]; }
         }
         __syncthreads();
         for (int r = tid; r < nrays; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
@@ -640,17 +707,24 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     const unsigned short *ord = sorted ? order : nullptr;
     const int strips = box[10], strip_w = box[11];
     const bool fast = strips != 0;        // single-scan owner form (the sweep at the end of the kernel)
-    if (!fast) {
+    for (int ph = 0; ph < (fast ? 0 : phases); ++ph) {
+        int seg0 = 0, seg1 = nrays;
+        if (phases == 2) {
+            const int *o = ph ? box + 24 : box + 4;
+            wx0 = o[0]; wy0 = o[1]; W = o[2]; H = o[3]; covers = o[4] != 0; Hp2 = (H + 1) >> 1;
+            seg0 = ph ? box[35] : 0; seg1 = ph ? nrays : box[35];
+            if (ph) __syncthreads();                                  // the previous half's flush has read the window
+            if (tid == 0) box[9] = 0;
+        }
         for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
         __syncthreads();
         STAMP(2);                                   // sort + zero
         // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
         const int first_bad = box[15];
-        if (covers) nvis = cast_rays<true>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
-        else        nvis = cast_rays<false>(g, src, sc, l, s0, n, nrays, &box[9], ord, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
+        if (covers) nvis += cast_rays<true>(g, src, sc, l, s0, n, seg1 - seg0, &box[9], ord ? ord + seg0 : nullptr, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
+        else        nvis += cast_rays<false>(g, src, sc, l, s0, n, seg1 - seg0, &box[9], ord ? ord + seg0 : nullptr, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
         __syncthreads();
         STAMP(3);                                   // walk
-    }
 
     // flush: one wave per window row, lanes along y (contiguous in the [x][y] map), two cells per lane
     // every workgroup flushes the same part of the map: start each one at a different row so
@@ -659,6 +733,18 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     for (int rr = wave; rr < (fused ? 0 : W); rr += nwaves) {
         const int row = rr + rot < W ? rr + rot : rr + rot - W;
         size_t gbase = (size_t)(wx0 + row) * g.yw + wy0;
+        // The flush is bound by the chip's rate of global atomics (every workgroup of a replay adds its
+        // ~25 k touched cells to the same map: 6 M atomics per 1 000 scans at 4 scans per group, 20 us
+        // chip-wide): a dword of the window - two cells that are neighbours in the map row - goes out as ONE
+        // 64-bit add of (count0, count1 << 32).  A carry out of the low counter would need 2^32 passes.
+        if (pair64 && (wy0 & 1) == 0) {
+            for (int d = lane; d < Hp2; d += kWave) {
+                unsigned v = win[row * Hp2 + d];
+                if (v) atomicAdd(reinterpret_cast<unsigned long long *>(&pass[gbase + 2 * d]),
+                                 (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32));
+            }
+            continue;
+        }
         for (int d = lane; d < Hp2; d += kWave) {
             unsigned v = win[row * Hp2 + d];
             unsigned p0 = v & 0xffffu, p1 = v >> 16;
@@ -666,6 +752,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             if (p1) atomicAdd(&pass[gbase + 2 * d + 1], p1);          // p1 != 0 implies 2d+1 < H
         }
     }
+    }   // phases
     // Live pmap: this workgroup is the only writer of its map during the launch, so once its own
     // atomics (hits, out-of-window passes) have landed it finishes every cell its rays could have
     // touched - the bounding box of pass 1, clamped to the map - in one sweep: add the window's
@@ -1489,6 +1576,14 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
     for (int rr = wave; rr < W; rr += nwaves) {
         const int row = rr + rot < W ? rr + rot : rr + rot - W;
         size_t gbase = (size_t)(tx0 + row) * g.yw + ty0;
+        if ((gbase & 1) == 0) {                             // pairs of counters are aligned 8-byte words (see the window kernel)
+            for (int d = lane; d < Hp2; d += kWave) {
+                unsigned v = win[row * Hs + d];
+                if (v) atomicAdd(reinterpret_cast<unsigned long long *>(&pass[gbase + 2 * d]),
+                                 (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32));
+            }
+            continue;
+        }
         for (int d = lane; d < Hp2; d += kWave) {
             unsigned v = win[row * Hs + d];
             unsigned p0 = v & 0xffffu, p1 = v >> 16;
