@@ -379,6 +379,17 @@ struct ExplicitSource {
     }
 };
 
+// LDS byte address of a pointer into shared memory, and a fire-and-forget 32-bit add at such an address
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void lds_add_u32(unsigned addr, unsigned v)
+{
+    (void)__hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int wave_min_i32(int v)
 {
 #pragma unroll
@@ -426,6 +437,49 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
         int lx = ry.steep ? ry.y0 : ry.x0, ly = ry.steep ? ry.x0 : ry.y0;
         int hx = -1, hy = -1;
         double error = 0.0;                                           // bresenham.py:34
+#ifndef SLAM_NO_FAST_WALK
+        // A ray whose two end cells lie in the window stays in it (a Bresenham path never leaves the box
+        // of its ends): no bounds checks, the cell kept as ONE running halfword index, four steps per
+        // wave-wide loop test.  The path's last cell is the endpoint's cell (mapping.py:44-45); it takes the
+        // hit and no pass count, so the walk leaves it out: a reversed path (flag) starts one step in.
+        const int Hs = 2 * Hp2;
+        const bool safe = (unsigned)(sc[s].pcx - wx0) < (unsigned)W && (unsigned)(sc[s].pcy - wy0) < (unsigned)H &&
+                    (unsigned)(pox - wx0) < (unsigned)W && (unsigned)(poy - wy0) < (unsigned)H;
+        // (a wave that also holds rays which leave the window walks all its rays the checked way: two loops
+        // one after the other made the slowest workgroups - those whose half does not fit - slower)
+        if (!__any(!safe)) {
+            {
+                // the cell as the LDS byte address of its 16-bit counter: dword = address & ~3, the count's
+                // position in it from address bit 1 (9 VALU + 1 LDS instructions per step; 14 + 1 + the
+                // per-step lane mask before)
+                unsigned a2 = lds_addr(win) + 2u * (unsigned)((lx - wx0) * Hs + (ly - wy0));
+                const int da_k = 2 * (ry.steep ? 1 : Hs), da_y = 2 * (ry.steep ? ry.ystep * Hs : ry.ystep);
+                int rem = ry.dx;                                      // pass cells: all but the path's last
+                auto advance = [&]() {
+                    error += ry.derr;                                 // bresenham.py:51
+                    const bool stepy = error >= 0.5;                  // :53
+                    a2 += (unsigned)(da_k + (stepy ? da_y : 0));
+                    error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);   // :55 (minus 1.0, or minus 0.0: exact)
+                };
+                if (ry.flag) advance();                               // step 0 is the hit cell: start one step in
+                nvis += (unsigned)ry.dx + 1u;                         // every cell of the path is in the map
+                auto step = [&]() {
+                    lds_add_u32(a2 & ~3u, 1u << ((a2 << 3) & 31u));   // mapping.py:43
+                    advance();
+                };
+                for (;;) {                                            // four steps per wave-wide test, no lane mask inside
+                    const bool full = rem >= 4;
+                    if (!__any(full)) break;
+                    if (full) { step(); step(); step(); step(); rem -= 4; }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (rem > u) step();
+                atomicAdd(&hit[(size_t)pox * g.yw + poy], 1u);        // mapping.py:45
+            }
+            continue;
+        }
+#endif
         for (int k = 0; k <= ry.dx; ++k) {                            // :45
             bool last = k == klast;
             unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
