@@ -332,6 +332,7 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 #define SLAM_POLAR_MAX 24
 #endif
 constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes
+constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
 template <typename T> struct StoreSlack { static constexpr float ang = 2e-7f; };              // float64 points
 template <> struct StoreSlack<float> { static constexpr float ang = 1e-6f; };                // 2 x 2^-24 sqrt(2), doubled
@@ -343,7 +344,7 @@ struct PolarGeo {
 };
 
 template <int UNROLL>
-__device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n_tar, double sx, double sy, int seed,
+__device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
                                          bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big)
 {
     seed = min(max(seed, 0), n_tar - 1);
@@ -352,7 +353,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n
     int lo, hi;
     // the window of beam indices around beam j that holds every target closer than t_j; false: no usable window
     auto window = [&](int j, int &wlo, int &whi) -> bool {
-        const double2 ts = tarL[tslot(j)];
+        const double2 ts = tarP[j];
         const double U = dist2(sx, sy, ts.x, ts.y);
         const float ftx = (float)ts.x, fty = (float)ts.y;
         const float x2 = __fdividef((float)U * 1.000002f + 1e-30f, rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
@@ -385,10 +386,13 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n
         // test): 999 pairs alone 0.121 against 0.125 ms; a full chip is bound by issue and the rounding
         // of the windows to whole trips costs more than the shorter chain saves (10 000 pairs: 0.468
         // against 0.456 ms), so those launches take two per trip.
+        // (the candidates of a trip are read from the unpadded copy at p, p + 1, ...: no index arithmetic per
+        // candidate.  A trip may run past a1: what lies there is a target outside the window - strictly
+        // farther than the bound, it cannot win - or one of the NaN points behind the last beam.)
         if (UNROLL == 4) for (int k = a0; __any(k <= a1); k += 4) {
             if (k <= a1) {
-                const int k1 = min(k + 1, a1), k2 = min(k + 2, a1), k3 = min(k + 3, a1);   // (a repeated candidate cannot win: strict '<')
-                const double2 t0 = tarL[tslot(k)], t1 = tarL[tslot(k1)], t2 = tarL[tslot(k2)], t3 = tarL[tslot(k3)];
+                const double2 *t = tarP + k;
+                const double2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
                 const double d0 = dist2(sx, sy, t0.x, t0.y), d1 = dist2(sx, sy, t1.x, t1.y);
                 const double d2 = dist2(sx, sy, t2.x, t2.y), d3 = dist2(sx, sy, t3.x, t3.y);
                 bool c = d0 < best;
@@ -396,20 +400,19 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n
                 bj = c ? k : bj;
                 c = d1 < best;
                 best = fmin(best, d1);
-                bj = c ? k1 : bj;
+                bj = c ? k + 1 : bj;
                 c = d2 < best;
                 best = fmin(best, d2);
-                bj = c ? k2 : bj;
+                bj = c ? k + 2 : bj;
                 c = d3 < best;
                 best = fmin(best, d3);
-                bj = c ? k3 : bj;
+                bj = c ? k + 3 : bj;
             }
         }
         else for (int k = a0; __any(k <= a1); k += 2) {
             if (k <= a1) {
-                const double2 t0 = tarL[tslot(k)];
-                const int k1 = min(k + 1, a1);                       // (a repeated candidate cannot win: strict '<')
-                const double2 t1 = tarL[tslot(k1)];
+                const double2 *t = tarP + k;
+                const double2 t0 = t[0], t1 = t[1];
                 const double d0 = dist2(sx, sy, t0.x, t0.y);
                 const double d1 = dist2(sx, sy, t1.x, t1.y);
                 bool c = d0 < best;
@@ -417,13 +420,14 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarL, int n
                 bj = c ? k : bj;
                 c = d1 < best;
                 best = fmin(best, d1);
-                bj = c ? k1 : bj;
+                bj = c ? k + 1 : bj;
             }
         }
     };
-    scan(go ? 0 : 1, go ? e0 : 0);
+    const bool wraps = __any(go && (e0 >= 0 || s2 < n_tar));        // (rare: one wave-uniform test instead of two empty loops)
+    if (wraps) scan(go ? 0 : 1, go ? e0 : 0);
     scan(go ? m0 : 1, go ? m1 : 0);
-    scan(go ? s2 : 1, go ? n_tar - 1 : 0);
+    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0);
     best_d2 = best;
     best_j = bj;
 }
@@ -500,12 +504,16 @@ __device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsi
 }
 
 template <typename T>
-__device__ __forceinline__ void stage_points(const Cloud<T> &tar, int n_tar, double2 *tarL)
+__device__ __forceinline__ void stage_points(const Cloud<T> &tar, int n_tar, double2 *tarL, double2 *tarP = nullptr)
 {
     const int nb = nn_blocks(n_tar), npad = nb * kNNBlock;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int j = threadIdx.x; j < npad; j += blockDim.x)
-        tarL[tslot(j)] = j < n_tar ? tar.at(j) : make_double2(qnan, qnan);
+    for (int j = threadIdx.x; j < npad; j += blockDim.x) {
+        const double2 t = j < n_tar ? tar.at(j) : make_double2(qnan, qnan);
+        tarL[tslot(j)] = t;
+        if (tarP && j < n_tar) tarP[j] = t;
+    }
+    if (tarP && threadIdx.x < kPolarTail) tarP[n_tar + threadIdx.x] = make_double2(qnan, qnan);
 }
 
 __device__ __forceinline__ void stage_boxes(int n_tar, const double2 *tarL, Box *boxes, Box *boxes4)
@@ -548,6 +556,7 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
 constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collapsed-set exchange (two parities)
+__host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
 constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the reductions, two alternating buffers
 
 // Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles
@@ -622,10 +631,11 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
     Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
-    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar));                      // [2][kMaxWaves][8]
+    double2 *tarP = reinterpret_cast<double2 *>(smem + nn_lds_bytes(a.n_tar));                   // [n_tar + kPolarTail]: the target again, not padded (nn_polar)
+    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar));   // [2][kMaxWaves][8]
     unsigned *geo = reinterpret_cast<unsigned *>(red + kIcpRedDoubles);                          // [4] polar_probe; geo[3]: source set collapsed
     double *cref = reinterpret_cast<double *>(geo + 4);                                          // [2][4]: matched point of query 0, "all the same" flag
-    char *guard = smem + nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
+    char *guard = smem + nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
     lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -642,7 +652,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     }
 
     if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; }
-    stage_points(tar, n_tar, tarL);
+    stage_points(tar, n_tar, tarL, tarP);
     __syncthreads();                                                 // (geo is initialised for the probe)
     ISTAMP(10);
     stage_boxes(n_tar, tarL, boxes, boxes4);
@@ -711,7 +721,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
             double d2; int j;
             if (pg.inv_db > 0.0f) {                                  // wave-uniform: the target is a scan
                 bool big;
-                nn_polar<UNROLL>(tarL, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
+                nn_polar<UNROLL>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
                 // The few queries without a good match (newly visible surfaces; they come in runs of
                 // neighbouring beams: measured 1.3 % of the queries, in 10 % of the wave-queries, 8 lanes at
                 // a time) take the box search.  Tried and dropped: scanning the whole cloud for them
@@ -728,7 +738,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
                 nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, ok[q], d2, j);   // icp.py:67
             }
             seed[q] = j;                                             // next iteration's guess
-            double2 m = tarL[tslot(j)];
+            double2 m = tarP[j];
             mx[q] = m.x; my[q] = m.y;
             double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
             if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dist; }
@@ -835,7 +845,7 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
     int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
     if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
-    size_t lds = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
+    size_t lds = nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
 #ifdef SLAM_ICP_LDS_PAD
     if (a.B > 64) lds += SLAM_ICP_LDS_PAD;      // tuning experiments: fewer resident workgroups per CU
 #endif
