@@ -332,6 +332,7 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 #define SLAM_POLAR_MAX 24
 #endif
 constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes
+constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
 constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
 template <typename T> struct StoreSlack { static constexpr float ang = 2e-7f; };              // float64 points
@@ -368,19 +369,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db)) + 1;
         return small && whi - wlo < kPolarMax;
     };
-    const bool fits = window(seed, lo, hi);
-    // (tried: a second window around the beam that points at the query for lanes whose first one is
-    // too wide.  It never helps: the first iteration's guess IS that beam - source and target points of
-    // one index lie on one ray - and its 14 % wide lanes see a different surface than the target did)
-    big = active && !fits;
-    const bool go = active && !big;
-    // three index ranges in ascending order: wrapped from above | the window | wrapped from below
-    const int m0 = max(lo, 0), m1 = min(hi, n_tar - 1);
-    const int e0 = hi > n_tar - 1 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;         // [0, e0]
-    const int s2 = lo < 0 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;                // [s2, n_tar - 1]
-    double best = INFINITY;
-    int bj = 0;
-    auto scan = [&](int a0, int a1) {
+    auto scan = [&](int a0, int a1, double &best, int &bj) {
         // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
         // the chip is bound by the LATENCY of a trip (read, distance, compare chain, wave-wide loop
         // test): 999 pairs alone 0.121 against 0.125 ms; a full chip is bound by issue and the rounding
@@ -424,10 +413,40 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
             }
         }
     };
+    bool fits = window(seed, lo, hi);
+#ifndef SLAM_NO_PROBE
+    // (only in the launches that fill the chip - UNROLL 2, see below: there it saves instructions, 10 000 pairs
+    // 0.425 -> 0.405 ms; a lone 999-pair launch is bound by the latency of its longest solves and got
+    // SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter)
+    if (UNROLL == 2 && __any(active && !fits)) {
+        // A guess that bounds nothing useful - before the first update source and target point of one beam
+        // lie on ONE ray, and where the two scans see different surfaces there (14 % of the lanes, in 84 %
+        // of the wave-queries) the bound is the range jump - is replaced by the best of the 17 beams around
+        // it: the surface the query lies on is usually seen a few beams away (1.5 % of the lanes, 18 % of the
+        // wave-queries remain for the box search).  Any index is a valid guess: it only supplies the bound.
+        const bool need = active && !fits;
+        double pb = INFINITY;
+        int pj = seed;
+        scan(need ? max(seed - kPolarProbe, 0) : 1, need ? min(seed + kPolarProbe, n_tar - 1) : 0, pb, pj);
+        int lo1, hi1;
+        const bool fits1 = window(pj, lo1, hi1) && need;
+        lo = fits1 ? lo1 : lo;
+        hi = fits1 ? hi1 : hi;
+        fits = fits || fits1;
+    }
+#endif
+    big = active && !fits;
+    const bool go = active && !big;
+    // three index ranges in ascending order: wrapped from above | the window | wrapped from below
+    const int m0 = max(lo, 0), m1 = min(hi, n_tar - 1);
+    const int e0 = hi > n_tar - 1 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;         // [0, e0]
+    const int s2 = lo < 0 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;                // [s2, n_tar - 1]
+    double best = INFINITY;
+    int bj = 0;
     const bool wraps = __any(go && (e0 >= 0 || s2 < n_tar));        // (rare: one wave-uniform test instead of two empty loops)
-    if (wraps) scan(go ? 0 : 1, go ? e0 : 0);
-    scan(go ? m0 : 1, go ? m1 : 0);
-    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0);
+    if (wraps) scan(go ? 0 : 1, go ? e0 : 0, best, bj);
+    scan(go ? m0 : 1, go ? m1 : 0, best, bj);
+    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0, best, bj);
     best_d2 = best;
     best_j = bj;
 }
