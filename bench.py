@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--grid-group", type=int, default=-1,
                     help="scans per ray-cast workgroup (0: the library's choice; default: 12 when replays overlap, else 0)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
+    ap.add_argument("--icp-qpt", type=int, default=None, help="scan-matching queries per lane (default: 3 with several lanes, else the library's choice by batch size)")
     ap.add_argument("--lanes", type=int, default=None, help="contexts (stream sets) the replays alternate between")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1: map stage of a replay on a second stream, overlapping the next replay's scan matching")
@@ -233,7 +234,7 @@ class ReplayWorkload:
             ln.dr.ctx.set_option("pipeline", args.pipeline)
             # several replays share the chip: three queries per lane (fewest instructions); a lone
             # replay leaves the choice to the library (two: shortest launch)
-            ln.dr.ctx.set_option("icp_qpt", int(os.environ.get("SLAM_BENCH_QPT", 3 if n_lanes > 1 else 0)))
+            ln.dr.ctx.set_option("icp_qpt", args.icp_qpt if args.icp_qpt is not None else int(os.environ.get("SLAM_BENCH_QPT", 3 if n_lanes > 1 else 0)))
             ln.count = 0
             self.lanes.append(ln)
         self.dev = self.lanes[0].dr.dev
@@ -553,6 +554,22 @@ def main():
                      "kernel_ms_per_launch_overlapped": {k: fam[k][0] / fam[k][1] for k in ms},
                      "timed": "start/stop HIP events carried by every dispatch of all %d lanes; avg_launch_ms is the one-lane (stand-alone) duration, "
                               "the overlapped durations include the time a kernel shares the chip with the other lanes' kernels" % len(wl.contexts())})
+    if len(wl.contexts()) > 1 and hasattr(wl, "family_kernels"):
+        # Several launches share the chip: what the CHIP issued over the timed region, all kernels together
+        # (instruction counts per launch from the committed PMC passes; k_icp in the launch shape this run used)
+        tot, missing = 0.0, []
+        for f, (t_ms, n_l) in fam.items():
+            kk = wl.family_kernels.get(f)
+            pk = load_pmc(args.config, kk) if kk else {}
+            per = pk.get("valu_insts_per_launch_qpt3") if f == "icp" and pk.get("valu_insts_per_launch_qpt3") else pk.get("valu_insts_per_launch")
+            if per is None:
+                missing.append(f)
+            else:
+                tot += per * n_l
+        if not missing and elapsed > 0:
+            roofline["chip_valu_issue"] = {"achieved": tot / elapsed, "peak": F64_ISSUE_PEAK, "frac": tot / elapsed / F64_ISSUE_PEAK, "unit": "wave-instructions/s",
+                                           "note": "sum over ALL kernels of SQ_INSTS_VALU per launch (profiles/) x launches in the timed region / its duration: "
+                                                   "how busy the chip's vector issue was while %d replays overlapped" % len(wl.contexts())}
     iters = np.asarray(wl.iters)
     if "icp" in fam and fam["icp"][1]:
         # The figure below counts the distance evaluations an EXHAUSTIVE nearest-neighbour scan would

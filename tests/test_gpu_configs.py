@@ -191,6 +191,65 @@ def test_window_kernel_subwindow_sizes(slam, W, H, y_origin, live):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["interior_fits", "interior_too_large", "shifted_origins", "axis_rays", "one_half_empty", "odd_rows", "near_map_edge"])
+@pytest.mark.parametrize("group", [1, 4, 12])
+def test_window_kernel_direction_halves(slam, case, group):
+    """The window kernel's two direction halves (grid_mode 3): a group whose bounding box does not
+    fit the window gives the window to the rays that run towards larger x and to those that run towards
+    smaller x in turn.  Shapes: both halves fit / neither does (sub-rectangle + direct atomics) / scans of
+    a group whose origins lie on both sides of the first one's column / rays along the axes (an endpoint in
+    the origin's column belongs to the 'larger x' half) / all rays on one side / a map with an odd row
+    length (no paired 64-bit flush) / boxes clipped by the map's edge.  Counters, pmap and visit count
+    equal the oracle's after two passes."""
+    yw = 601 if case == "odd_rows" else 600
+    xw, scale, off_x, off_y = 640, 20.0, 16.0, 15.0
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", 3)
+    ctx.set_option("grid_group", group)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, context=ctx)
+    rng = np.random.default_rng(7)
+    B = 12
+    W, H = (300, 280) if case == "interior_too_large" else (260, 250)
+    x_lo, y_lo = (8, 12) if case != "near_map_edge" else (xw - 200, yw - 190)
+    scans = []
+    for b in range(B):
+        cxc, cyc = x_lo + W // 2, y_lo + H // 2
+        if case == "shifted_origins":
+            cxc += int(rng.integers(-12, 13)); cyc += int(rng.integers(-12, 13))
+        if case == "one_half_empty":
+            cxc = x_lo
+        if case == "axis_rays":
+            cells = [(cxc, y_lo), (cxc, y_lo + H - 1), (x_lo, cyc), (x_lo + W - 1, cyc), (cxc, cyc + 1), (cxc + 1, cyc), (cxc - 1, cyc), (cxc, cyc),
+                     (x_lo, y_lo), (x_lo + W - 1, y_lo + H - 1), (cxc + 1, y_lo), (cxc - 1, y_lo + H - 1)] * 8
+            ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells]); oy = np.array([(c[1] + 0.5) / scale - off_y for c in cells])
+            cx, cy = (cxc + 0.5) / scale - off_x, (cyc + 0.5) / scale - off_y
+        else:
+            x_hi, y_hi = x_lo + W - 1, y_lo + H - 1
+            if case == "near_map_edge":
+                x_hi += 60; y_hi += 70                                # endpoints beyond the map: their rays leave it
+            cells = [(x_hi, y) for y in range(y_lo, y_hi + 1, 3)] + [(x, y_hi) for x in range(x_lo, x_hi + 1, 3)]
+            cells += [(x_lo, y) for y in range(y_lo, y_hi + 1, 3)] + [(x, y_lo) for x in range(x_lo, x_hi + 1, 3)]
+            cells = cells[b % 3:] + cells[:b % 3]
+            ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells]); oy = np.array([(c[1] + 0.5) / scale - off_y for c in cells])
+            cx, cy = (cxc + 0.5) / scale - off_x, (cyc + 0.5) / scale - off_y
+        scans.append((ox, oy, cx, cy))
+    n = min(len(s_[0]) for s_ in scans)
+    OX = np.stack([s_[0][:n] for s_ in scans]); OY = np.stack([s_[1][:n] for s_ in scans])
+    CX = np.array([s_[2] for s_ in scans]); CY = np.array([s_[3] for s_ in scans])
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    for _ in range(2):
+        g.update_host(OX, OY, CX, CY)
+        for b in range(B):
+            og.update(OX[b], OY[b], CX[b], CY[b])
+    ctx.check_status()
+    r = g.read(0, want=("pmap", "pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt), (case, group)
+    assert np.array_equal(r["pmap"], og.pmap) and g.visits() == og.visits
+    assert int(r["pass"].sum()) > 100000
+    g.close()
+    ctx.close()
+
+
 def test_dist_replay_sharded_world1_hip_runner(slam, syn):
     """dist.replay_sharded with the HIP runner (the multi-GPU entry of configs[3]) on one
     rank: same poses as the oracle, gathered result == local result."""

@@ -40,5 +40,12 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_su
         > /dev/null 2>> "$OUT/pmc.err" || { echo "pmc pass $i failed"; tail -5 "$OUT/pmc.err"; exit 1; }
     echo "$grp" > "$OUT/pmc_$i/counters.txt"
 done
+if [ "$CFG" = replay ]; then
+    # instruction count of k_icp in the launch shape the overlapped default run uses (three queries per lane)
+    # shellcheck disable=SC2086
+    rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_6" -- python3 "$R/bench.py" $COMMON $PSTEPS --lanes 1 --no-parity --icp-qpt 3 \
+        > /dev/null 2>> "$OUT/pmc.err" || { echo "pmc pass 6 failed"; tail -5 "$OUT/pmc.err"; exit 1; }
+    echo "SQ_INSTS_VALU icp_qpt=3" > "$OUT/pmc_6/counters.txt"
+fi
 python3 "$R/bench.py" --config $CFG $STEPS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG" "$CFG"

@@ -64,7 +64,10 @@ def main():
         for k in sorted(local):
             lines.append("%s %s" % (k, {c: "%.4g (n=%d)" % (sum(v) / len(v), len(v)) for c, v in sorted(local[k].items())}))
             for c, v in local[k].items():
-                per[k][c] = v
+                if "icp_qpt=3" in grp:                # the extra pass in the overlapped run's launch shape: kept apart
+                    per[k][c + "@qpt3"] = v
+                else:
+                    per[k][c] = v
         lines.append("")
     traffic = {}
     lines.append("# derived per launch -> profiles/pmc_traffic.json")
@@ -84,6 +87,8 @@ def main():
                       "source": "profiles/%s_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE x2 correction (MI355X_MICROARCH.md HBM section)" % tag,
                       "valu_busy_frac": busy, "valu_insts_per_launch": avg("SQ_INSTS_VALU"),
                       "lds_insts_per_launch": avg("SQ_INSTS_LDS")}
+        if c.get("SQ_INSTS_VALU@qpt3"):
+            traffic[k]["valu_insts_per_launch_qpt3"] = avg("SQ_INSTS_VALU@qpt3")
         lines.append("%s HBM %.3f MB VALU busy %s" % (k, hbm / 1e6, "n/a" if busy is None else "%.1f %%" % (100 * busy)))
     open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
     allcfg = {}
