@@ -1599,6 +1599,70 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
         uint32_t word = bw[w];
         int y = rec.y0 + ystep * ((int)ts.prefix[rid * kTileWords + w] + __popc(word & ((1u << (k0 & 31)) - 1u)));
         word >>= (k0 & 31);
+#ifndef SLAM_TILE_OLD_WALK
+        // The cell of walk step k as the LDS byte address of its 16-bit counter, advanced incrementally (while
+        // the ray is outside the tile's rows the address is virtual: it is only used inside them).  The path's
+        // last cell takes the hit and no pass count (mapping.py:44-45): it is the ray's first or last step and is
+        // trimmed off the range here.
+        const int HW = 2 * Hs;                                       // 16-bit counters per window row
+        const int da_k = 2 * (steep ? 1 : HW), da_y = 2 * (steep ? ystep * HW : ystep);
+        unsigned a2 = lds_addr(win) + 2u * (unsigned)(steep ? (y - b0) * HW + (rec.x0 + k0 - a0) : (rec.x0 + k0 - a0) * HW + (y - b0));
+        int k = k0, kk1 = k1 - (klast == k1 ? 1 : 0);
+        if (klast == k0) {                                           // (klast == 0 == k0: the word holds bit 0 still)
+            const unsigned bit = word & 1u;
+            y += bit ? ystep : 0;
+            a2 += (unsigned)(da_k + (bit ? da_y : 0));
+            word >>= 1;
+            ++k;
+            if ((k & 31) == 0 && k <= kk1) word = bw[++w];           // (only for a one-bit first word: dx >= 1, so never; kept for safety)
+        }
+        bool gone = false;
+        while (k <= kk1 && !gone) {
+            const int kend = min(kk1, (w << 5) + 31);
+            const uint32_t next = (w + 1) * 32 <= k1 ? bw[w + 1] : 0u;   // in flight while this word is walked
+            const int nb = kend - k + 1;
+            const uint32_t bits = nb == 32 ? word : (word & ((1u << nb) - 1u));
+            const int pc = __popc(bits);
+            const int yafter = y + ystep * pc;                       // y of the step after this word's last
+            if (ystep > 0 ? yafter < b0 : yafter > b1) {             // the whole word stays short of the tile's rows
+                y = yafter; k = kend + 1; a2 += (unsigned)(nb * da_k + pc * da_y); word = next; ++w;
+                continue;
+            }
+            // every step of the word inside the rows (y is monotone: both ends inside): no checks, four steps
+            // per wave-wide test
+            const int ylast = yafter - ((bits >> (nb - 1)) & 1u ? ystep : 0);   // y AT the word's last step
+            const bool inside = y >= b0 && y <= b1 && ylast >= b0 && ylast <= b1;
+            if (__any(inside)) {
+                int rem = inside ? nb : 0;
+                auto step = [&]() {
+                    lds_add_u32(a2 & ~3u, 1u << ((a2 << 3) & 31u));
+                    a2 += (unsigned)(da_k + ((word & 1u) ? da_y : 0));
+                    word >>= 1;
+                };
+                for (;;) {
+                    const bool full = rem >= 4;
+                    if (!__any(full)) break;
+                    if (full) { step(); step(); step(); step(); rem -= 4; }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (rem > u) step();
+                if (inside) { y = yafter; k = kend + 1; word = next; ++w; }
+            }
+            if (!inside) {                                           // the word in which the ray enters or leaves the rows
+                for (; k <= kend; ++k) {
+                    if (ystep > 0 ? y > b1 : y < b0) { gone = true; break; }   // left the tile for good
+                    if (y >= b0 && y <= b1) lds_add_u32(a2 & ~3u, 1u << ((a2 << 3) & 31u));
+                    const unsigned bit = word & 1u;
+                    y += bit ? ystep : 0;
+                    a2 += (unsigned)(da_k + (bit ? da_y : 0));
+                    word >>= 1;
+                }
+                word = next;
+                ++w;
+            }
+        }
+#else
         // cell of walk step k in window coordinates, advanced incrementally
         int wa = rec.x0 + k0 - a0;                                   // along the walk axis: 0 .. a1 - a0
         bool gone = false;
@@ -1624,6 +1688,7 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
             word = next;
             ++w;
         }
+#endif
     }
     __syncthreads();
     const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)W);
