@@ -493,7 +493,7 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
             bool stepy = error >= 0.5;                                // :53
             lx += ax_x + (stepy ? ay_x : 0);
             ly += ax_y + (stepy ? ay_y : 0);
-            error = stepy ? error - 1.0 : error;                      // :55
+            error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);    // :55 (minus 1.0, or minus 0.0: exact)
         }
         if ((unsigned)hx < (unsigned)g.xw && (unsigned)hy < (unsigned)g.yw) atomicAdd(&hit[(size_t)hx * g.yw + hy], 1u);   // mapping.py:45
     }
@@ -545,7 +545,7 @@ __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src 
             const bool stepy = error >= 0.5;                          // :53
             lx += ax_x + (stepy ? ay_x : 0);
             ly += ax_y + (stepy ? ay_y : 0);
-            error = stepy ? error - 1.0 : error;                      // :55
+            error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);    // :55 (minus 1.0, or minus 0.0: exact)
         }
     }
     return nvis;
@@ -1186,7 +1186,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
                         const bool stepy = o.error >= 0.5;           // :53
                         o.h += o.dh_k + (stepy ? o.dh_y : 0);
                         o.lx += o.dlx_k + (stepy ? o.dlx_y : 0);
-                        o.error = stepy ? o.error - 1.0 : o.error;   // :55
+                        o.error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);   // :55 (minus 1.0, or minus 0.0: exact)
                         ++o.k;
                     }
                 }
@@ -1480,15 +1480,16 @@ __global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratc
                 if (k0 <= dx) {
                     uint32_t word = 0;
                     const int nb = min(32, dx - k0 + 1);
+                    // (whole words: the steps past the ray's end are computed and masked off - nothing reads
+                    // the recurrence after them - so there is no lane mask per step)
 #pragma unroll 8
                     for (int b = 0; b < 32; ++b) {
-                        if (b < nb) {
-                            error += derr;                            // bresenham.py:51
-                            const bool stepy = error >= 0.5;          // :53
-                            error = stepy ? error - 1.0 : error;      // :55
-                            word |= stepy ? (1u << b) : 0u;
-                        }
+                        error += derr;                                // bresenham.py:51
+                        const bool stepy = error >= 0.5;              // :53
+                        error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);   // :55 (minus 1.0, or minus 0.0: exact)
+                        word |= stepy ? (1u << b) : 0u;
                     }
+                    if (nb < 32) word &= (1u << nb) - 1u;
                     pw[k0 >> 5] = (unsigned short)count;
                     bw[k0 >> 5] = word;
                     if (k0 + 32 > dx) before_last = count + __popc(word & ((1u << (dx - k0)) - 1u));   // y advances before step dx
