@@ -344,7 +344,7 @@ struct PolarGeo {
     float slack;      // angular slack of the stored points (radians)
 };
 
-template <int UNROLL>
+template <int UNROLL, bool PROBE>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
                                          bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big)
 {
@@ -372,9 +372,9 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     auto scan = [&](int a0, int a1, double &best, int &bj) {
         // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
         // the chip is bound by the LATENCY of a trip (read, distance, compare chain, wave-wide loop
-        // test): 999 pairs alone 0.121 against 0.125 ms; a full chip is bound by issue and the rounding
-        // of the windows to whole trips costs more than the shorter chain saves (10 000 pairs: 0.468
-        // against 0.456 ms), so those launches take two per trip.
+        // test): 999 pairs alone 0.121 against 0.125 ms.  (With the padded copy and clamped indices the wider
+        // trip cost a full chip 2.6 % - the windows are rounded to whole trips; reading the unpadded copy it
+        // no longer does, and every launch shape up to three queries per lane takes four.)
         // (the candidates of a trip are read from the unpadded copy at p, p + 1, ...: no index arithmetic per
         // candidate.  A trip may run past a1: what lies there is a target outside the window - strictly
         // farther than the bound, it cannot win - or one of the NaN points behind the last beam.)
@@ -415,10 +415,11 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     };
     bool fits = window(seed, lo, hi);
 #ifndef SLAM_NO_PROBE
-    // (only in the launches that fill the chip - UNROLL 2, see below: there it saves instructions, 10 000 pairs
-    // 0.425 -> 0.405 ms; a lone 999-pair launch is bound by the latency of its longest solves and got
-    // SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter)
-    if (UNROLL == 2 && __any(active && !fits)) {
+    // (PROBE: in the launch shape for a full chip - three queries per lane - where it saves instructions:
+    // 10 000 pairs 0.425 -> 0.395 ms.  A lone 999-pair launch with two queries per lane is bound by the latency
+    // of its longest solves and got SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter:
+    // a workgroup waits for its slowest wave, and 65 % of the pairs still have one that needs the box search.)
+    if (PROBE && __any(active && !fits)) {
         // A guess that bounds nothing useful - before the first update source and target point of one beam
         // lie on ONE ray, and where the two scans see different surfaces there (14 % of the lanes, in 84 %
         // of the wave-queries) the bound is the range jump - is replaced by the best of the 17 beams around
@@ -641,7 +642,7 @@ constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the r
 #else
 #define SLAM_ICP_ATTR
 #endif
-template <typename T, int QPT, int UNROLL>
+template <typename T, int QPT, int UNROLL, bool PROBE>
 __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
 {
     ISTAMP_DECL;
@@ -740,7 +741,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
             double d2; int j;
             if (pg.inv_db > 0.0f) {                                  // wave-uniform: the target is a scan
                 bool big;
-                nn_polar<UNROLL>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
+                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
                 // The few queries without a good match (newly visible surfaces; they come in runs of
                 // neighbouring beams: measured 1.3 % of the queries, in 10 % of the wave-queries, 8 lanes at
                 // a time) take the box search.  Tried and dropped: scanning the whole cloud for them
@@ -870,24 +871,26 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 #endif
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
-#define SLAM_ICP_CASE(Q, U)                                                                                     \
+#define SLAM_ICP_CASE(Q, U, P)                                                                                  \
     {                                                                                                           \
         if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U>),                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q, U>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                     \
+        SLAM_LAUNCH((k_icp<T, Q, U, P>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                     \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid
     // once per pair - was measured: 12 % fewer instructions, but 0.28 instead of 0.20 ms alone and
     // no faster with replays overlapping: dropped)
-    // (candidates per trip of the beam-window search: see nn_polar - four where latency counts, two where issue does)
-    if (qpt <= 1) SLAM_ICP_CASE(1, 4)
-    else if (qpt <= 2) SLAM_ICP_CASE(2, 4)
-    else if (qpt <= 3) SLAM_ICP_CASE(3, 2)
-    else if (qpt <= 4) SLAM_ICP_CASE(4, 2)
-    else if (qpt <= 8) SLAM_ICP_CASE(8, 2)
+    // (candidates per trip of the beam-window search and the re-guess of useless first guesses: see nn_polar.  Four
+    // per trip are as fast as two when the chip is full and faster when it is not - four overlapping 999-pair
+    // replays 8.5 -> 8.9 M scans/s - since the candidates come from the unpadded copy.)
+    if (qpt <= 1) SLAM_ICP_CASE(1, 4, false)
+    else if (qpt <= 2) SLAM_ICP_CASE(2, 4, false)
+    else if (qpt <= 3) SLAM_ICP_CASE(3, 4, true)
+    else if (qpt <= 4) SLAM_ICP_CASE(4, 2, true)
+    else if (qpt <= 8) SLAM_ICP_CASE(8, 2, true)
     else return hipErrorInvalidValue;   // n_src > 8192
 #undef SLAM_ICP_CASE
     return hipGetLastError();
