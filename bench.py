@@ -559,6 +559,8 @@ def main():
         # (instruction counts per launch from the committed PMC passes; k_icp in the launch shape this run used)
         tot, missing = 0.0, []
         for f, (t_ms, n_l) in fam.items():
+            if not n_l:
+                continue
             kk = wl.family_kernels.get(f)
             pk = load_pmc(args.config, kk) if kk else {}
             per = pk.get("valu_insts_per_launch_qpt3") if f == "icp" and pk.get("valu_insts_per_launch_qpt3") else pk.get("valu_insts_per_launch")
