@@ -247,9 +247,89 @@ __device__ __forceinline__ double dist2(double sx, double sy, double tx, double 
     return fma(dy, dy, dx * dx);
 }
 
+// ---------------------------------------------------------------------------------
+// The reference orders candidates by DISTANCE, sqrt of the square (icp.py:102-103), and sqrt maps up to
+// three neighbouring doubles to one value: two candidates whose squares differ in the last places can be
+// a TIE for it - the lower index wins - where the squares are ordered.  The searches below order by the
+// square (no square root per candidate) and watch for the one event that can make the two orderings
+// disagree: a candidate replacing a best that is less than 2^-50 above it (a class of equal roots spans
+// at most 2^-51 of its value).  A lane that saw one re-does its query the reference's way over the whole
+// target (nn_exact): rare - mathematically tied neighbours of symmetric or quantised scans whose squares
+// round differently - and exact; tests/golden/g10_sqrt_ties.npz holds replays whose iteration count
+// depends on it.
+// ---------------------------------------------------------------------------------
+constexpr double kTieAbove = 1.0 + 0x1p-50;
+
+#ifndef SLAM_BOX_UNROLL
+#define SLAM_BOX_UNROLL 4
+#endif
+struct Best {
+    double d2;                // smallest square so far
+    int j;
+    unsigned long long ambm;  // lanes that saw the event, as a wave-wide mask (two scalar instructions per candidate:
+                              // a per-lane bool costs a dozen vector ones in what the compiler makes of it)
+    __device__ __forceinline__ void start() { d2 = INFINITY; j = 0; ambm = 0ull; }
+    __device__ __forceinline__ void take(double d, int k)
+    {
+        const bool c = d < d2;
+#ifndef SLAM_NO_TIE_TRACK
+        const double dk = d * kTieAbove;                             // (off the compare chain: it depends on the candidate alone)
+        ambm |= __ballot(c) & ~__ballot(dk < d2);
+#endif
+        d2 = fmin(d2, d);                                            // NaN never lowers it
+        j = c ? k : j;
+    }
+    // the same, with the event handed out as a wave mask: the caller ORs the masks of a trip into `ambm` after its
+    // last candidate, so that the scalar instructions do not sit between the vector ones (a wave issues in order:
+    // a scalar AND right behind the compare that feeds it stalls the vector pipeline of a lone launch)
+    __device__ __forceinline__ unsigned long long take_m(double d, int k)
+    {
+        const bool c = d < d2;
+#ifndef SLAM_NO_TIE_TRACK
+        const unsigned long long ev = __ballot(c) & ~__ballot(d * kTieAbove < d2);
+#else
+        const unsigned long long ev = 0ull;
+#endif
+        d2 = fmin(d2, d);
+        j = c ? k : j;
+        return ev;
+    }
+    // the same with the two comparisons handed out, for callers that fold them into `ambm` outside a lane-masked region
+    __device__ __forceinline__ void take(double d, int k, bool &c, bool &clearly)
+    {
+        c = d < d2;
+        clearly = d * kTieAbove < d2;
+        d2 = fmin(d2, d);
+        j = c ? k : j;
+    }
+    __device__ __forceinline__ void fold(bool c, bool clearly) { ambm |= __ballot(c) & ~__ballot(clearly); }
+    __device__ __forceinline__ bool amb() const { return (ambm >> (threadIdx.x & 63)) & 1ull; }
+};
+
+// the reference's own loop for one query (icp.py:99-105) over an LDS cloud (slot of point j: j + (j >> 4)
+// when `padded`).  Its square root per candidate costs ~20 registers: it lives in k_nn and in the EXACT
+// variant of k_icp, not in the hot one (there it took occupancy from 5 to 4 waves per SIMD, 10 000 pairs
+// 0.39 -> 0.47 ms).
+struct NNHit { double d2; int j; };
+__device__ __forceinline__ NNHit nn_exact(const double2 *tab, bool padded, int n_tar, double sx, double sy)
+{
+    double ms = INFINITY, md2 = INFINITY;
+    int mj = 0;
+    for (int j = 0; j < n_tar; ++j) {
+        const double2 t = tab[padded ? j + (j >> 4) : j];
+        const double d2 = dist2(sx, sy, t.x, t.y);
+        const double s = sqrt(d2);
+        const bool c = s < ms;                                       // strict: the first of equal distances; NaN, inf never win
+        ms = c ? s : ms;
+        md2 = c ? d2 : md2;
+        mj = c ? j : mj;
+    }
+    return NNHit{md2, mj};
+}
+
 __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, const Box *__restrict__ boxes,
                                           const Box *__restrict__ boxes4, int nblocks, int n_tar, double sx, double sy,
-                                          int seed, bool first_iter, bool active, double &best_d2, int &best_j)
+                                          int seed, bool first_iter, bool active, double &best_d2, int &best_j, bool &amb)
 {
     seed = min(max(seed, 0), n_tar - 1);
     double U;
@@ -266,8 +346,8 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
     }
     double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
-    double best = INFINITY;
-    int bj = 0;
+    Best b;
+    b.start();
     for (int base = 0; base < nblocks; base += 32) {
         const int cnt = min(32, nblocks - base);
         unsigned mask = 0u;
@@ -291,22 +371,26 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
                 const int blk = base + __ffs((int)mask) - 1;
                 mask &= mask - 1u;
                 const double2 *t = tarL + blk * kNNStride;
-                const double before = best;
+                const double before = b.d2;
                 int kk = 0;
 #pragma unroll
                 for (int k = 0; k < kNNBlock; ++k) {
                     double2 tk = t[k];
-                    double d2 = dist2(sx, sy, tk.x, tk.y);
-                    bool c = d2 < best;
-                    best = fmin(best, d2);       // NaN never lowers it
-                    kk = c ? k : kk;
+                    const double d = dist2(sx, sy, tk.x, tk.y);
+                    const bool c = d < b.d2;
+#ifndef SLAM_NO_TIE_TRACK
+                    b.ambm |= __ballot(c) & ~__ballot(d * kTieAbove < b.d2);
+#endif
+                    b.d2 = fmin(b.d2, d);                            // NaN never lowers it
+                    kk = c ? k : kk;                                 // (the index within the block: constants)
                 }
-                bj = (best < before) ? blk * kNNBlock + kk : bj;
+                b.j = (b.d2 < before) ? blk * kNNBlock + kk : b.j;
             }
         }
     }
-    best_d2 = best;
-    best_j = bj;
+    best_d2 = b.d2;
+    best_j = b.j;
+    amb = b.amb();
 }
 
 // ---------------------------------------------------------------------------------
@@ -346,7 +430,7 @@ struct PolarGeo {
 
 template <int UNROLL, bool PROBE>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
-                                         bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big)
+                                         bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big, bool &amb)
 {
     seed = min(max(seed, 0), n_tar - 1);
     const float fsx = (float)sx, fsy = (float)sy;
@@ -369,7 +453,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db)) + 1;
         return small && whi - wlo < kPolarMax;
     };
-    auto scan = [&](int a0, int a1, double &best, int &bj) {
+    auto scan = [&](int a0, int a1, Best &b) {
         // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
         // the chip is bound by the LATENCY of a trip (read, distance, compare chain, wave-wide loop
         // test): 999 pairs alone 0.121 against 0.125 ms.  (With the padded copy and clamped indices the wider
@@ -378,39 +462,26 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         // (the candidates of a trip are read from the unpadded copy at p, p + 1, ...: no index arithmetic per
         // candidate.  A trip may run past a1: what lies there is a target outside the window - strictly
         // farther than the bound, it cannot win - or one of the NaN points behind the last beam.)
+        // Every lane runs every trip of its wave - no lane mask inside the loop, so the tie bookkeeping stays in
+        // scalar registers - but a lane past its own range reads the NaN points behind the last beam (one
+        // address for all such lanes: a broadcast, where reading on through real targets cost LDS bandwidth).
         if (UNROLL == 4) for (int k = a0; __any(k <= a1); k += 4) {
-            if (k <= a1) {
-                const double2 *t = tarP + k;
-                const double2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-                const double d0 = dist2(sx, sy, t0.x, t0.y), d1 = dist2(sx, sy, t1.x, t1.y);
-                const double d2 = dist2(sx, sy, t2.x, t2.y), d3 = dist2(sx, sy, t3.x, t3.y);
-                bool c = d0 < best;
-                best = fmin(best, d0);                               // NaN never lowers it
-                bj = c ? k : bj;
-                c = d1 < best;
-                best = fmin(best, d1);
-                bj = c ? k + 1 : bj;
-                c = d2 < best;
-                best = fmin(best, d2);
-                bj = c ? k + 2 : bj;
-                c = d3 < best;
-                best = fmin(best, d3);
-                bj = c ? k + 3 : bj;
-            }
+            const int kc = k <= a1 ? k : n_tar;
+            const double2 *t = tarP + kc;
+            const double2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+            const double d0 = dist2(sx, sy, t0.x, t0.y), d1 = dist2(sx, sy, t1.x, t1.y);
+            const double d2 = dist2(sx, sy, t2.x, t2.y), d3 = dist2(sx, sy, t3.x, t3.y);
+            const unsigned long long e0 = b.take_m(d0, kc), e1 = b.take_m(d1, kc + 1), e2 = b.take_m(d2, kc + 2), e3 = b.take_m(d3, kc + 3);
+            b.ambm |= (e0 | e1) | (e2 | e3);
         }
         else for (int k = a0; __any(k <= a1); k += 2) {
-            if (k <= a1) {
-                const double2 *t = tarP + k;
-                const double2 t0 = t[0], t1 = t[1];
-                const double d0 = dist2(sx, sy, t0.x, t0.y);
-                const double d1 = dist2(sx, sy, t1.x, t1.y);
-                bool c = d0 < best;
-                best = fmin(best, d0);                               // NaN never lowers it
-                bj = c ? k : bj;
-                c = d1 < best;
-                best = fmin(best, d1);
-                bj = c ? k + 1 : bj;
-            }
+            const int kc = k <= a1 ? k : n_tar;
+            const double2 *t = tarP + kc;
+            const double2 t0 = t[0], t1 = t[1];
+            const double d0 = dist2(sx, sy, t0.x, t0.y);
+            const double d1 = dist2(sx, sy, t1.x, t1.y);
+            const unsigned long long e0 = b.take_m(d0, kc), e1 = b.take_m(d1, kc + 1);
+            b.ambm |= e0 | e1;
         }
     };
     bool fits = window(seed, lo, hi);
@@ -426,11 +497,12 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         // it: the surface the query lies on is usually seen a few beams away (1.5 % of the lanes, 18 % of the
         // wave-queries remain for the box search).  Any index is a valid guess: it only supplies the bound.
         const bool need = active && !fits;
-        double pb = INFINITY;
-        int pj = seed;
-        scan(need ? max(seed - kPolarProbe, 0) : 1, need ? min(seed + kPolarProbe, n_tar - 1) : 0, pb, pj);
+        Best pb;
+        pb.start();
+        pb.j = seed;
+        scan(need ? max(seed - kPolarProbe, 0) : 1, need ? min(seed + kPolarProbe, n_tar - 1) : 0, pb);
         int lo1, hi1;
-        const bool fits1 = window(pj, lo1, hi1) && need;
+        const bool fits1 = window(pb.j, lo1, hi1) && need;
         lo = fits1 ? lo1 : lo;
         hi = fits1 ? hi1 : hi;
         fits = fits || fits1;
@@ -442,14 +514,15 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     const int m0 = max(lo, 0), m1 = min(hi, n_tar - 1);
     const int e0 = hi > n_tar - 1 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;         // [0, e0]
     const int s2 = lo < 0 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;                // [s2, n_tar - 1]
-    double best = INFINITY;
-    int bj = 0;
+    Best b;
+    b.start();
     const bool wraps = __any(go && (e0 >= 0 || s2 < n_tar));        // (rare: one wave-uniform test instead of two empty loops)
-    if (wraps) scan(go ? 0 : 1, go ? e0 : 0, best, bj);
-    scan(go ? m0 : 1, go ? m1 : 0, best, bj);
-    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0, best, bj);
-    best_d2 = best;
-    best_j = bj;
+    if (wraps) scan(go ? 0 : 1, go ? e0 : 0, b);
+    scan(go ? m0 : 1, go ? m1 : 0, b);
+    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0, b);
+    best_d2 = b.d2;
+    best_j = b.j;
+    amb = go && b.amb();
 }
 
 // LDS image of the target: float64 (x, y) pairs padded with NaN points to a whole number
@@ -642,9 +715,14 @@ constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the r
 #else
 #define SLAM_ICP_ATTR
 #endif
-template <typename T, int QPT, int UNROLL, bool PROBE>
+template <typename T, int QPT, int UNROLL, bool PROBE, bool EXACT>
 __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
 {
+    // EXACT: the second launch of every batch.  It re-does, with the reference's own nearest-neighbour loop
+    // (nn_exact), the pairs in which the first launch saw a best undercut its predecessor by less than a class
+    // of equal distances (a.redo[b], see "Best") - none on noisy scans, a few per cent of the pairs on scans
+    // with quantised ranges - and returns at once for all others.
+    if (EXACT && !a.redo[blockIdx.x]) return;
     ISTAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblocks = nn_blocks(a.n_tar);
@@ -733,15 +811,20 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     ISTAMP(14);
     double pre_error = 0.0, mean_error = 0.0;
     int iters = 0, par = 0;
+    bool amb_any = false;
     for (int it = 0; it < a.max_iter; ++it) {
         double mx[QPT], my[QPT];
         double v[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             double d2; int j;
-            if (pg.inv_db > 0.0f) {                                  // wave-uniform: the target is a scan
+            bool amb = false;
+            if (EXACT) {
+                const NNHit h = nn_exact(tarP, false, ok[q] ? n_tar : 0, sx[q], sy[q]);
+                d2 = h.d2; j = h.j;
+            } else if (pg.inv_db > 0.0f) {                           // wave-uniform: the target is a scan
                 bool big;
-                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big);                        // icp.py:67
+                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big, amb);          // icp.py:67
                 // The few queries without a good match (newly visible surfaces; they come in runs of
                 // neighbouring beams: measured 1.3 % of the queries, in 10 % of the wave-queries, 8 lanes at
                 // a time) take the box search.  Tried and dropped: scanning the whole cloud for them
@@ -749,14 +832,16 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
                 // launch), and searching a lane's queries together in one wave-wide loop (4.55e7).
                 ISTAMP_BIG(it, big);
                 if (__any(big)) {
-                    double d2b; int jb;
-                    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, big, d2b, jb);
+                    double d2b; int jb; bool ambb;
+                    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, big, d2b, jb, ambb);
                     d2 = big ? d2b : d2;
                     j = big ? jb : j;
+                    amb = big ? ambb : amb;
                 }
             } else {
-                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, ok[q], d2, j);   // icp.py:67
+                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, ok[q], d2, j, amb);   // icp.py:67
             }
+            amb_any |= amb;                                          // -> a.redo[b]: the EXACT launch re-does this pair
             seed[q] = j;                                             // next iteration's guess
             double2 m = tarP[j];
             mx[q] = m.x; my[q] = m.y;
@@ -832,6 +917,10 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     }
     block_sum<4>(w, red + (par ^= 1) * kMaxWaves * 8, nwaves, wave, lane);
     if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+    if (a.redo) {
+        const int flag = EXACT ? 0 : __syncthreads_or(amb_any ? 1 : 0);
+        if (tid == 0) a.redo[b] = flag;
+    }
     if (tid == 0) {
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = a.T_out + 9 * (long)b;
@@ -874,11 +963,19 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
 #define SLAM_ICP_CASE(Q, U, P)                                                                                  \
     {                                                                                                           \
         if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P>),                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P, false>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q, U, P>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                     \
+        SLAM_LAUNCH((k_icp<T, Q, U, P, false>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                 \
+        if (a.redo) {                                                                                           \
+            if (lds > 64 * 1024) {                                                                              \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, 2, false, true>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+                if (e != hipSuccess) return e;                                                                  \
+            }                                                                                                   \
+            SLAM_LAUNCH((k_icp<T, Q, 2, false, true>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);          \
+        }                     \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid
     // once per pair - was measured: 12 % fewer instructions, but 0.28 instead of 0.20 ms alone and
@@ -925,7 +1022,9 @@ __global__ void __launch_bounds__(256) k_nn(const T *src, const T *tar, int n_sr
     const T *s = src + (long)b * 2 * n_src;
     double sx = ok ? ld(s, i) : 0.0, sy = ok ? ld(s, (long)n_src + i) : 0.0;
     double d2; int j;
-    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx, sy, i, true, ok, d2, j);
+    bool amb;
+    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx, sy, i, true, ok, d2, j, amb);
+    if (amb) { const NNHit h = nn_exact(tarL, true, n_tar, sx, sy); d2 = h.d2; j = h.j; }
     if (ok) {
         dist[(long)b * n_src + i] = (d2 < INFINITY) ? sqrt(d2) : 0.0;
         idx[(long)b * n_src + i] = j;

@@ -81,6 +81,7 @@ struct IcpArgs {
     int32_t *iters_out;        // nullable [B]
     double *err_out;           // nullable [B]
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
+    int32_t *redo = nullptr;   // [B] scratch: pairs the EXACT launch must re-do (see k_icp); null: no second launch
     int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
 };
 

@@ -35,6 +35,10 @@ def lib():
         L = C.CDLL(build())
         L.orc_laser_to_points.argtypes = [_fp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]
         L.orc_find_nearest.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _ip]
+        L.orc_set_nn_rule.argtypes = [C.c_int]
+        L.orc_set_nn_rule.restype = None
+        L.orc_nn_rule_splits.argtypes = [C.c_int]
+        L.orc_nn_rule_splits.restype = C.c_long
         L.orc_get_transform.argtypes = [_dp, _dp, _dp, _dp, C.c_int, _dp]
         L.orc_icp_process.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, C.POINTER(C.c_double)]
         L.orc_icp_process.restype = C.c_int
@@ -168,6 +172,16 @@ class Grid:
 
 def pass_count_threshold(free_inc=0.01, thresh=10.0):
     return lib().orc_pass_count_threshold(free_inc, thresh)
+
+
+def set_nn_rule(rule):
+    """0: candidates ordered by distance (the reference), 1: by the fused square (the device kernels)."""
+    lib().orc_set_nn_rule(int(rule))
+
+
+def nn_rule_splits(reset=True):
+    """Queries since the last reset whose nearest neighbour differs between the two orderings."""
+    return int(lib().orc_nn_rule_splits(1 if reset else 0))
 
 
 def replay(ranges, angle_min, angle_max, grid=None, max_iter=30, tolerance=0.001, pose0=(0.0, 0.0, 0.0), threads=1,

@@ -44,13 +44,29 @@ void orc_laser_to_points(const float *ranges, const double *cos_t, const double 
 /* a-4: W12m/icp.py:90-114.  For every source point the first target point at the
  * smallest Euclidean distance (strict '<', :103).  A NaN or inf distance never wins,
  * leaving distance 0 / index 0 (:96-97). */
+/* Which ordering decides: 0 = the reference's (the distance, sqrt of the fused square), 1 = the device
+ * kernels' (the fused square itself; DESIGN.md "ordering of sub-ulp near-ties").  They pick the same target
+ * unless two squares differ in the last places and share a square root; orc_nn_rule_splits() counts the
+ * queries for which they did not (since the last reset), whatever the rule in force - so a test can tell
+ * "the documented difference occurred in this input" from "something else is wrong". */
+static int g_nn_rule = 0;
+static long g_nn_splits = 0;
+void orc_set_nn_rule(int rule) { g_nn_rule = rule; }
+long orc_nn_rule_splits(int reset)
+{
+    long v = g_nn_splits;
+    if (reset) g_nn_splits = 0;
+    return v;
+}
+
 void orc_find_nearest(const double *sx, const double *sy, int n, const double *tx, const double *ty,
                       int m, double *dist, int32_t *idx)
 {
+    long splits = 0;
     for (int i = 0; i < n; ++i) {
-        double min_dist = INFINITY;
-        idx[i] = 0;
-        dist[i] = 0.0;
+        double min_dist = INFINITY, min_d2 = INFINITY;
+        int j_ref = 0, j_dev = 0;
+        double d_ref = 0.0, d_dev = 0.0;
         for (int j = 0; j < m; ++j) {
             double dx = sx[i] - tx[j];
             double dy = sy[i] - ty[j];
@@ -58,13 +74,26 @@ void orc_find_nearest(const double *sx, const double *sy, int n, const double *t
              * arithmetic: fma(x1, x1, x0*x0) in the NumPy / OpenBLAS the golden vectors were made with
              * (tests/test_nn_near_ties.py checks that it still is; the fused and the unfused square differ
              * in the last place for a quarter of all inputs, which decides near-ties of symmetric clouds) */
-            double d = sqrt(fma(dy, dy, dx * dx));
+            double d2 = fma(dy, dy, dx * dx);
+            double d = sqrt(d2);
             if (d < min_dist) {
                 min_dist = d;
-                idx[i] = j;
-                dist[i] = d;
+                j_ref = j;
+                d_ref = d;
+            }
+            if (d2 < min_d2 && d2 < INFINITY) {                     /* (an infinite distance never wins, as above) */
+                min_d2 = d2;
+                j_dev = j;
+                d_dev = d;
             }
         }
+        splits += j_ref != j_dev;
+        idx[i] = g_nn_rule ? j_dev : j_ref;
+        dist[i] = g_nn_rule ? d_dev : d_ref;
+    }
+    if (splits) {
+#pragma omp atomic
+        g_nn_splits += splits;
     }
 }
 
