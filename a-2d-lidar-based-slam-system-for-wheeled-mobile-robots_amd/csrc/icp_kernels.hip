@@ -441,11 +441,13 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         const double2 ts = tarP[j];
         const double U = dist2(sx, sy, ts.x, ts.y);
         const float ftx = (float)ts.x, fty = (float)ts.y;
-        const float x2 = __fdividef((float)U * 1.000002f + 1e-30f, rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
+        // (v_rcp_f32 / v_sqrt_f32: one unit in the last place, 6e-8, against margins of 1e-6 and more; the IEEE
+        // division the compiler makes of `/` or __fdividef here is ten instructions, twice per window)
+        const float x2 = ((float)U * 1.000002f + 1e-30f) * __builtin_amdgcn_rcpf(rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
         const bool small = x2 < 0.25f;                               // NaN: false
-        const float x = __fsqrt_rn(x2) * 1.000001f;
+        const float x = __builtin_amdgcn_sqrtf(x2) * 1.000001f;
         const float alpha = x * (1.0f + x2 * (0.16666667f + 0.1f * x2)) * 1.000002f + geo.slack;   // >= asin(x) for x < 0.5
-        const float y = __fdividef(ftx * fsy - fty * fsx, ftx * fsx + fty * fsy);       // tan(delta), |delta| <= 30 degrees
+        const float y = (ftx * fsy - fty * fsx) * __builtin_amdgcn_rcpf(ftx * fsx + fty * fsy);       // tan(delta), |delta| <= 30 degrees
         const float y3 = y * y * y * 0.33333334f;
         const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;          // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
         const float dlo = (y >= 0.0f ? y - y3 : y) - 4e-6f;
