@@ -986,7 +986,13 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // per trip are as fast as two when the chip is full and faster when it is not - four overlapping 999-pair
     // replays 8.5 -> 8.9 M scans/s - since the candidates come from the unpadded copy.)
     if (qpt <= 1) SLAM_ICP_CASE(1, 4, false)
-    else if (qpt <= 2) SLAM_ICP_CASE(2, 4, false)
+#ifndef SLAM_Q2_U
+#define SLAM_Q2_U 4
+#endif
+#ifndef SLAM_Q2_P
+#define SLAM_Q2_P false
+#endif
+    else if (qpt <= 2) SLAM_ICP_CASE(2, SLAM_Q2_U, SLAM_Q2_P)
     else if (qpt <= 3) SLAM_ICP_CASE(3, 4, true)
     else if (qpt <= 4) SLAM_ICP_CASE(4, 2, true)
     else if (qpt <= 8) SLAM_ICP_CASE(8, 2, true)
