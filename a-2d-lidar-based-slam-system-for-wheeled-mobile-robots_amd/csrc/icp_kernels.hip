@@ -266,8 +266,10 @@ constexpr double kTieAbove = 1.0 + 0x1p-50;
 struct Best {
     double d2;                // smallest square so far
     int j;
-    unsigned long long ambm;  // lanes that saw the event, as a wave-wide mask (two scalar instructions per candidate:
-                              // a per-lane bool costs a dozen vector ones in what the compiler makes of it)
+    unsigned long long ambm;  // lanes that saw the event, as a wave-wide mask (two scalar instructions per candidate: a
+                              // per-lane bool costs a dozen vector ones in what the compiler makes of it; a per-lane
+                              // counter fed by the compares as carries - two vector adds - was slower still: 10 000
+                              // pairs 0.505 against 0.460 ms, and 0.395 ms without any bookkeeping)
     __device__ __forceinline__ void start() { d2 = INFINITY; j = 0; ambm = 0ull; }
     __device__ __forceinline__ void take(double d, int k)
     {

@@ -27,7 +27,23 @@ def short(name):
     n = name.replace("void ", "")
     n = n.split("(")[0]
     n = n.replace("slam::", "")
-    return n.split("<")[0]
+    base = n.split("<")[0]
+    # the second launch of every scan-matching batch (k_icp<..., EXACT = true>: re-does the pairs flagged for
+    # distance ties, returns at once for the others) is kept apart from the kernel that does the work
+    if base == "k_icp" and "<" in n and n.rstrip(">").split(",")[-1].strip() == "true":
+        return "k_icp_exact"
+    return base
+
+
+def newest(pattern):
+    """Files of the LATEST run only: gpurun_out/ accumulates the output of earlier calls (rocprofv3 names its files
+    by process id), and kernels renamed since would be averaged into today's."""
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        return []
+    latest = max(files, key=os.path.getmtime)
+    pid = os.path.basename(latest).split("_")[0]
+    return [f for f in files if os.path.basename(f).split("_")[0] == pid and os.path.dirname(f) == os.path.dirname(latest)]
 
 
 def main():
@@ -38,7 +54,7 @@ def main():
     dst = os.path.join(src, "profiles")
     os.makedirs(dst, exist_ok=True)
     for which in ("default", "1lane"):
-        f = glob.glob(os.path.join(src, "trace_" + which, "**", "*kernel_stats.csv"), recursive=True)
+        f = newest(os.path.join(src, "trace_" + which, "**", "*kernel_stats.csv"))
         if f:
             shutil.copy(f[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, which)))
         b = os.path.join(src, "bench_%s_under_rocprof.json" % which)
@@ -55,7 +71,7 @@ def main():
         grp = open(os.path.join(d, "counters.txt")).read().strip() if os.path.exists(os.path.join(d, "counters.txt")) else d
         lines.append("## --pmc " + grp)
         local = collections.defaultdict(lambda: collections.defaultdict(list))
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
                 if not k.startswith("k_"):
