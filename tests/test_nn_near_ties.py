@@ -135,6 +135,12 @@ def test_kernels_pick_what_the_reference_picks(g9, g10):
         poses, T, it = slam.replay_host(r, -span / 2, span / 2)
         assert np.array_equal(it, g10["c%d_iters" % c]), (c, it, g10["c%d_iters" % c])
         assert np.max(np.abs(T - g10["c%d_T" % c])) < 1e-9
+        # the drop-in call (one pair per launch, point clouds instead of raw scans: the box search)
+        ang = np.linspace(-span / 2, span / 2, r.shape[1])
+        pcs = [np.vstack((np.cos(ang) * x.astype(np.float64), np.sin(ang) * x.astype(np.float64), np.ones(r.shape[1]))) for x in r]
+        for k in range(1, len(pcs)):
+            Tk = icp.process(pcs[k - 1], pcs[k])
+            assert icp.last_iters == g10["c%d_iters" % c][k - 1] and np.max(np.abs(Tk - g10["c%d_T" % c][k - 1])) < 1e-9
         for points in ("f32", "f16"):
             poses, T, it = slam.replay_host(r, -span / 2, span / 2, dtype=points)
             _, oT, oit, _ = checks.replay_reference(r, -span / 2, span / 2, None, points, 30, 1e-3, threads=1)
