@@ -1028,8 +1028,8 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);
     int *box = reinterpret_cast<int *>(smem + win_sc_bytes(1));
-    int *hist = box + 16;
-    unsigned short *order = reinterpret_cast<unsigned short *>(hist + kSortBins);
+    int *hist = box + kWinBoxInts;                                   // [2][kSortBins]: (direction half,) length bin
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + 2 * kSortBins);
     unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);
     char *guard = reinterpret_cast<char *>(win) + (size_t)win_cells * 2;
     lds_guard_fill(guard);
@@ -1046,7 +1046,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
         src.scan_const(l, 0, g, sc[0]);
         box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; *wg_visits = 0ull; box[14] = 0; box[15] = INT_MAX;
     }
-    if (tid < kSortBins) hist[tid] = 0;
+    if (tid < 2 * kSortBins) hist[tid] = 0;
     __syncthreads();
     STAMP(0);
     const ScanConst c0 = sc[0];
@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     // pass 1: endpoints, bounding box, length histogram
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
     for (int r = tid; r < n; r += blockDim.x) {
-        int pox, poy, len = 0, b2 = 0;
+        int pox = 0, poy = 0, len = 0, b2 = 0;
         if (src.ray(l, 0, r, c0, g, pox, poy, b2)) {
             bx0 = min(bx0, min(pox, c0.pcx)); bx1 = max(bx1, max(pox, c0.pcx));
             by0 = min(by0, min(poy, c0.pcy)); by1 = max(by1, max(poy, c0.pcy));
@@ -1064,7 +1064,8 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
         // beams before it have been applied when the exception leaves update(), and the error is that
         // beam's)
         if (b2) atomicMin(&box[15], r);
-        int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1);      // longest first
+        // longest first; rays that run towards larger x behind those that run towards smaller x (see `halves`)
+        int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1) + (pox >= c0.pcx ? kSortBins : 0);
         bins[r] = (unsigned short)bin;
         atomicAdd(&hist[bin], 1);
     }
@@ -1089,20 +1090,32 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
             S = (int)(((long)Wb * Ha + win_cells - 1) / win_cells); Ws = (Wb + S - 1) / S;
             while ((long)Ws * Ha > win_cells) { ++S; Ws = (Wb + S - 1) / S; }   // (the host made sure one row fits: yw <= win_cells)
         }
-        box[4] = x0; box[5] = ya; box[6] = x1 - x0 + 1; box[7] = Ha; box[10] = S; box[11] = Ws;
+        // Direction halves (as in k_grid_update_win): a box that needs two or more strips is cut at the origin's
+        // column instead when both sides then fit - a ray never crosses that column, so each ray is walked once,
+        // in the half it runs into, without a bounds test; strips walk some rays again and test every step.
+        int halves = 0;
+        const int split = min(max(c0.pcx, x0), x1);
+        if (S >= 2 && (long)max(split - x0 + 1, x1 - split + 1) * Ha <= win_cells) { halves = 1; S = 2; }
+        box[4] = x0; box[5] = ya; box[6] = x1 - x0 + 1; box[7] = Ha; box[10] = S; box[11] = Ws; box[8] = halves; box[9] = split;
     }
-    if (wave == 0) {                                                 // counting sort by length bin: scan of the histogram
-        int a = hist[2 * lane], b2 = hist[2 * lane + 1], tot = a + b2, inc = tot;
+    if (wave == 0) {                                                 // counting sort by (half, length bin): scan of the histogram
+        int h4[4], tot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { h4[u] = hist[4 * lane + u]; tot += h4[u]; }
+        int inc = tot;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
-        hist[2 * lane] = inc - tot;
-        hist[2 * lane + 1] = inc - tot + a;
+        int run = inc - tot;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { hist[4 * lane + u] = run; run += h4[u]; }
     }
     __syncthreads();
     for (int r = tid; r < n; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
     __syncthreads();
     STAMP(1);
     const int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7], strips = box[10], strip_w = box[11];
+    const bool halves = box[8] != 0;
+    const int split = box[9];
     const int Hp2 = H >> 1;
 
     // this lane's rays: sorted rays tid, tid + blockDim, ...
@@ -1128,7 +1141,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
         const bool inmap = (unsigned)c0.pcx < (unsigned)g.xw && (unsigned)c0.pcy < (unsigned)g.yw &&
                            (unsigned)pox[j] < (unsigned)g.xw && (unsigned)poy[j] < (unsigned)g.yw;
         if (!inmap) { kind[j] = 3u; unsafe = 1; continue; }
-        kind[j] = (rr.steep && rr.ystep < 0 && strips > 1) ? 2u : 1u;
+        kind[j] = (rr.steep && rr.ystep < 0 && strips > 1 && !halves) ? 2u : 1u;
         nvis += (unsigned)rr.dx + 1u;                                // every cell of the path is in the map (mapping.py:41)
         ry[j].start(rr, H);
     }
@@ -1140,7 +1153,8 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     const int qrow = H >> 2;                                         // quads per window row (H is a multiple of 16)
     const unsigned qinv = qrow ? (unsigned)((0x100000000ull + (unsigned)qrow - 1) / (unsigned)qrow) : 0u;   // q / qrow == umulhi(q, qinv)
     for (int strip = 0; strip < strips; ++strip) {
-        const int sx0 = wx0 + strip * strip_w, SW = min(strip_w, wx0 + W - sx0), total = SW * qrow;
+        const int sx0 = halves ? (strip ? split : wx0) : wx0 + strip * strip_w;
+        const int SW = halves ? (strip ? wx0 + W - split : split - wx0 + 1) : min(strip_w, wx0 + W - sx0), total = SW * qrow;
         if (strip) __syncthreads();                                  // the previous strip's sweep has read the window
         {
             uint4 *w4 = reinterpret_cast<uint4 *>(win);
@@ -1152,6 +1166,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
 #pragma unroll
         for (int j = 0; j < kOwnerRays; ++j) {
             if (kind[j] == 0u) continue;
+            if (halves && (pox[j] >= c0.pcx ? 1 : 0) != strip) continue;     // (the origin's column lies in both halves)
             const unsigned wx = (unsigned)(pox[j] - sx0), wy = (unsigned)(poy[j] - wy0);
             if (wx < (unsigned)SW && wy < (unsigned)H) {             // (the strips tile the bounding box clamped to the map)
                 atomicOr(&win[wx * Hp2 + (wy >> 1)], 0x8000u << ((wy & 1u) * 16u));
@@ -1159,7 +1174,39 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
                 if (kind[j] == 3u) ++nvis;
             }
         }
-        // walk (bresenham.py:45-55): a ray continues from where it stands while it is in this strip
+        // walk (bresenham.py:45-55)
+        if (halves) {
+            // every ray of this half, start to end, unchecked (see cast_rays): all its cells lie in the half's window
+#pragma unroll
+            for (int j = 0; j < kOwnerRays; ++j) {
+                const OwnRay &o = ry[j];
+                const bool mine = kind[j] == 1u && (pox[j] >= c0.pcx ? 1 : 0) == strip;
+                if (!__any(mine)) continue;
+                unsigned a2 = lds_addr(win) + 2u * (unsigned)((o.lx - sx0) * H + (o.ly - wy0));
+                const int da_k = 2 * o.dh_k, da_y = 2 * o.dh_y;
+                double error = 0.0;
+                int rem = mine ? o.kend : 0;                         // pass cells: all but the path's last
+                auto advance = [&]() {
+                    error += o.derr;
+                    const bool stepy = error >= 0.5;
+                    a2 += (unsigned)(da_k + (stepy ? da_y : 0));
+                    error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);
+                };
+                if (mine && o.klast == 0) advance();                 // a reversed path: its first walk step is the hit cell
+                auto step = [&]() {
+                    lds_add_u32(a2 & ~3u, 1u << ((a2 << 3) & 31u));   // mapping.py:43
+                    advance();
+                };
+                for (;;) {
+                    const bool full = rem >= 4;
+                    if (!__any(full)) break;
+                    if (full) { step(); step(); step(); step(); rem -= 4; }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (rem > u) step();
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < kOwnerRays; ++j) {
             OwnRay &o = ry[j];
@@ -1199,6 +1246,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
 #pragma unroll
             for (int j = 0; j < kOwnerRays; ++j) {
                 if (kind[j] != 3u) continue;
+                if (halves && (pox[j] >= c0.pcx ? 1 : 0) != strip) continue;   // (walked once, in the half they run into)
                 Ray rr;
                 ray_setup(c0.pcx, c0.pcy, pox[j], poy[j], rr);
                 const int klast = rr.flag ? 0 : rr.dx;
