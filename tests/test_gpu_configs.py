@@ -304,14 +304,18 @@ def _ring(x_lo, x_hi, y_lo, y_hi, step=1):
     return cells
 
 
-@pytest.mark.parametrize("case", ["fits", "two_strips", "three_strips_many_rays", "leaves_map", "origin_outside", "too_many_rays"])
+@pytest.mark.parametrize("case", ["fits", "two_strips", "three_strips_many_rays", "leaves_map", "origin_outside", "too_many_rays",
+                                  "halves_origin_off_centre", "halves_one_side_too_wide", "halves_rays_leave_map", "halves_axis_rays"])
 def test_single_scan_owner_kernel_fans(slam, case):
     """The single-scan owner kernel (one scan into a map with a live pmap: Mapping.update, the
     particle maps): full-circle fans so that every octant, the reference's endpoint swap and
     lines stepping towards -x occur; bounding boxes of one, two and three window strips; one and
     two rays per lane; rays that leave the map; an origin outside the map; more rays than the
-    kernel takes (falls back to the group kernel).  Two passes: the second adds to non-zero
-    counters and meets a pmap that is no longer 50.  Everything must equal the oracle."""
+    kernel takes (falls back to the group kernel); boxes of two strips that are cut at the origin's column
+    instead (both sides fit: "two_strips", an origin off centre, rays that leave the map, rays along the axes
+    whose endpoint lies in the origin's column) and one whose wider side does not fit (strips after all).  Two
+    passes: the second adds to non-zero counters and meets a pmap that is no longer 50.  Everything must
+    equal the oracle."""
     xw, yw, scale, off_x, off_y = 440, 400, 20.0, 11.0, 10.0
     org = (215, 203)
     if case == "fits":
@@ -325,6 +329,18 @@ def test_single_scan_owner_kernel_fans(slam, case):
     elif case == "origin_outside":
         org = (-30, 180)
         cells = _ring(40, 300, 100, 320, 4) + [(-50, 181), (-30, 181)]
+    elif case == "halves_origin_off_centre":
+        org = (150, 230)
+        cells = _ring(60, 330, 90, 300, 3)                         # 91 | 181 columns x 224-cell rows: both sides fit
+    elif case == "halves_one_side_too_wide":
+        org = (75, 140)
+        cells = _ring(60, 330, 90, 300, 3)                         # 16 | 256 columns: the right side alone exceeds the window
+    elif case == "halves_rays_leave_map":
+        org = (215, 203)
+        cells = _ring(60, 330, 90, 300, 3) + _ring(-40, 480, 120, 280, 12)   # the box clamps to the map: still two halves
+    elif case == "halves_axis_rays":
+        org = (200, 200)
+        cells = _ring(60, 330, 90, 300, 3) + [(200, y) for y in range(90, 301, 2)] + [(x, 200) for x in range(60, 331, 2)] + [(200, 200)]
     else:
         cells = _ring(100, 400, 50, 350, 1)                        # 1 204 rays > 1 024
     ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells])
