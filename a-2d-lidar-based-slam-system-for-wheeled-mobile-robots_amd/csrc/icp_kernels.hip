@@ -253,23 +253,22 @@ __device__ __forceinline__ double dist2(double sx, double sy, double tx, double 
 // a TIE for it - the lower index wins - where the squares are ordered.  The searches below order by the
 // square (no square root per candidate) and watch for the one event that can make the two orderings
 // disagree: a candidate replacing a best that is less than 2^-50 above it (a class of equal roots spans
-// at most 2^-51 of its value).  A lane that saw one re-does its query the reference's way over the whole
-// target (nn_exact): rare - mathematically tied neighbours of symmetric or quantised scans whose squares
-// round differently - and exact; tests/golden/g10_sqrt_ties.npz holds replays whose iteration count
+// at most 2^-51 of its value).  k_nn re-does the query of a lane that saw one the reference's way over the
+// whole target (nn_exact); k_icp marks the PAIR (a.redo[b]) and the second launch of the batch re-does it with
+// nn_exact in every iteration.  Rare - mathematically tied neighbours of symmetric or quantised scans whose
+// squares round differently - and exact; tests/golden/g10_sqrt_ties.npz holds replays whose iteration count
 // depends on it.
 // ---------------------------------------------------------------------------------
 constexpr double kTieAbove = 1.0 + 0x1p-50;
 
-#ifndef SLAM_BOX_UNROLL
-#define SLAM_BOX_UNROLL 4
-#endif
 struct Best {
     double d2;                // smallest square so far
     int j;
     unsigned long long ambm;  // lanes that saw the event, as a wave-wide mask (two scalar instructions per candidate: a
                               // per-lane bool costs a dozen vector ones in what the compiler makes of it; a per-lane
                               // counter fed by the compares as carries - two vector adds - was slower still: 10 000
-                              // pairs 0.505 against 0.460 ms, and 0.395 ms without any bookkeeping)
+                              // pairs 0.505 against 0.460 ms, and 0.395 ms without any bookkeeping; collecting the
+                              // masks of a trip and combining them behind a scheduling barrier changed nothing)
     __device__ __forceinline__ void start() { d2 = INFINITY; j = 0; ambm = 0ull; }
     __device__ __forceinline__ void take(double d, int k)
     {
@@ -281,30 +280,6 @@ struct Best {
         d2 = fmin(d2, d);                                            // NaN never lowers it
         j = c ? k : j;
     }
-    // the same, with the event handed out as a wave mask: the caller ORs the masks of a trip into `ambm` after its
-    // last candidate, so that the scalar instructions do not sit between the vector ones (a wave issues in order:
-    // a scalar AND right behind the compare that feeds it stalls the vector pipeline of a lone launch)
-    __device__ __forceinline__ unsigned long long take_m(double d, int k)
-    {
-        const bool c = d < d2;
-#ifndef SLAM_NO_TIE_TRACK
-        const unsigned long long ev = __ballot(c) & ~__ballot(d * kTieAbove < d2);
-#else
-        const unsigned long long ev = 0ull;
-#endif
-        d2 = fmin(d2, d);
-        j = c ? k : j;
-        return ev;
-    }
-    // the same with the two comparisons handed out, for callers that fold them into `ambm` outside a lane-masked region
-    __device__ __forceinline__ void take(double d, int k, bool &c, bool &clearly)
-    {
-        c = d < d2;
-        clearly = d * kTieAbove < d2;
-        d2 = fmin(d2, d);
-        j = c ? k : j;
-    }
-    __device__ __forceinline__ void fold(bool c, bool clearly) { ambm |= __ballot(c) & ~__ballot(clearly); }
     __device__ __forceinline__ bool amb() const { return (ambm >> (threadIdx.x & 63)) & 1ull; }
 };
 
@@ -475,8 +450,10 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
             const double2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
             const double d0 = dist2(sx, sy, t0.x, t0.y), d1 = dist2(sx, sy, t1.x, t1.y);
             const double d2 = dist2(sx, sy, t2.x, t2.y), d3 = dist2(sx, sy, t3.x, t3.y);
-            const unsigned long long e0 = b.take_m(d0, kc), e1 = b.take_m(d1, kc + 1), e2 = b.take_m(d2, kc + 2), e3 = b.take_m(d3, kc + 3);
-            b.ambm |= (e0 | e1) | (e2 | e3);
+            b.take(d0, kc);
+            b.take(d1, kc + 1);
+            b.take(d2, kc + 2);
+            b.take(d3, kc + 3);
         }
         else for (int k = a0; __any(k <= a1); k += 2) {
             const int kc = k <= a1 ? k : n_tar;
@@ -484,8 +461,8 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
             const double2 t0 = t[0], t1 = t[1];
             const double d0 = dist2(sx, sy, t0.x, t0.y);
             const double d1 = dist2(sx, sy, t1.x, t1.y);
-            const unsigned long long e0 = b.take_m(d0, kc), e1 = b.take_m(d1, kc + 1);
-            b.ambm |= e0 | e1;
+            b.take(d0, kc);
+            b.take(d1, kc + 1);
         }
     };
     bool fits = window(seed, lo, hi);
