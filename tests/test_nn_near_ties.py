@@ -145,3 +145,36 @@ def test_kernels_pick_what_the_reference_picks(g9, g10):
             poses, T, it = slam.replay_host(r, -span / 2, span / 2, dtype=points)
             _, oT, oit, _ = checks.replay_reference(r, -span / 2, span / 2, None, points, 30, 1e-3, threads=1)
             assert np.array_equal(it, oit) and np.max(np.abs(T - oT.reshape(T.shape))) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qpt", [1, 2, 3])
+@pytest.mark.parametrize("points", ["f64", "f16"])
+def test_distance_ties_in_the_batched_launch_shapes(qpt, points):
+    """The launch shapes of large batches (two and three queries per lane: beam-window search with four candidates
+    per trip, the re-guess of useless first guesses, the box search behind them, the second launch that re-does
+    flagged pairs) on a 120-scan staircase stream in which the reference's tie rule decides dozens of queries
+    (counted by the oracle): iteration counts exact, transforms to 1e-9, for every pair."""
+    from oracle import checks
+    slam = pkg()
+    rng = np.random.default_rng(6)
+    scans, n, span = 120, 360, 6.28318
+    r = np.round(rng.uniform(0.5, 8.0, size=(scans, 1)) + np.cumsum(rng.integers(-1, 2, size=(scans, n)), axis=1) * 0.25, 2).clip(0.25, 30).astype(np.float32)
+    co.nn_rule_splits()
+    _, oT, oit, _ = checks.replay_reference(r, -span / 2, span / 2, None, points, 30, 1e-3, threads=4)
+    splits = co.nn_rule_splits()
+    if points == "f64":                                              # (rounding the points to f16 breaks the symmetries)
+        assert splits >= 30, splits                                  # the input does exercise the rule ...
+        co.set_nn_rule(1)
+        try:
+            _, oT1, oit1, _ = checks.replay_reference(r, -span / 2, span / 2, None, points, 30, 1e-3, threads=4)
+        finally:
+            co.set_nn_rule(0)
+        assert not np.array_equal(oit, oit1)                         # ... and ordering by squares would change iteration counts
+        assert int((np.abs(oT - oT1).reshape(len(oit), -1).max(axis=1) > 1e-9).sum()) >= 5
+    dr = slam.DeviceReplay(r, -span / 2, span / 2, dtype=points)
+    dr.ctx.set_option("icp_qpt", qpt)
+    dr.run()
+    poses, T, it = dr.results()
+    assert np.array_equal(it[0], oit), (np.nonzero(it[0] != oit)[0][:10], it[0][:10], oit[:10])
+    assert np.max(np.abs(T[0] - oT.reshape(T[0].shape))) < 1e-9
