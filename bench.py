@@ -115,7 +115,8 @@ def parse():
     if args.warmup is None:
         args.warmup = 5 if args.config == "replay" else 2
     if args.grid_group < 0:
-        args.grid_group = 12 if (args.lanes > 1 and args.config == "replay") else 0
+        args.grid_group = 0       # the library's choice (8 scans per ray-cast workgroup for a 1 000-scan replay; with the
+                                  # direction halves that beats the 12 which round 1 used when replays overlap: 8.5 vs 8.1 M)
     return args
 
 
@@ -230,7 +231,7 @@ class ReplayWorkload:
                 ln.pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
                 ln.ring_T = torch.empty((2,) + tuple(ln.dr.T.shape), dtype=torch.float64, device=ln.dr.dev)
             ln.dr.ctx.set_option("grid_mode", args.grid_mode)
-            ln.dr.ctx.set_option("grid_group", args.grid_group if n_lanes > 1 or args.grid_group != 12 else 0)
+            ln.dr.ctx.set_option("grid_group", args.grid_group)
             ln.dr.ctx.set_option("pipeline", args.pipeline)
             # several replays share the chip: three queries per lane (fewest instructions); a lone
             # replay leaves the choice to the library (two: shortest launch)
