@@ -1403,7 +1403,7 @@ static int pick_group(int group, long total_scans, int scans_per_traj, int n)
     if (gmax < 1) return 0;                                          // n too large for the packed counters
     if (group <= 0) {
         long want = (total_scans + 127) / 128;
-        group = (int)std::min<long>(std::max<long>(want, 1), 16);
+        group = (int)std::min<long>(std::max<long>(want, 1), 12);   // (5 000-scan replays, four overlapping: 12 -> 9.3, 16 -> 8.9 M scans/s)
     }
     group = std::min(std::min(group, gmax), std::max(scans_per_traj, 1));
     return group;
