@@ -104,7 +104,9 @@ int slam_scan_to_points_dev(slam_ctx *ctx, const float *ranges, const double *co
                             int B, int n, int clip_inf, int dtype, void *pts_out);
 
 /* Replaces ICP.findNearest(src, tar) (W12m/icp.py:90-114): brute-force nearest
- * neighbour, lowest index on ties, (distance 0, index 0) when nothing compares less
+ * neighbour, lowest index on ties OF THE DISTANCE - the reference compares sqrt of the
+ * fused square, so squares that differ in the last places but share a square root tie too
+ * (tests/golden/g9, g10) - and (distance 0, index 0) when nothing compares less
  * than inf.  src [B][2][n_src], tar [B][2][n_tar]; dist [B][n_src], idx [B][n_src]. */
 int slam_nn(slam_ctx *ctx, const void *src, const void *tar, int B, int n_src, int n_tar, int dtype,
             double *dist, int32_t *idx);
