@@ -380,7 +380,7 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // dot(t_j, s), so k - j lies in [(delta - alpha) / dbeta, (delta + alpha) / dbeta] - typically 2-6
 // beams instead of the 30-40 points + 15 boxes the box search touches (measured on the benchmark
 // scans: median 6 candidates per query, 90 % <= 9).  The window is evaluated in float32 with
-// every rounding pushed outwards (plus one beam of slack on either side and the angular slack
+// every rounding pushed outwards (plus the angular slack
 // of points rounded to their storage type), the candidates inside it are compared exactly as
 // everywhere else (float64 dist2, ascending index, strict '<'), and a ray outside it holds only
 // points strictly farther than U: the result is bit-identical to the exhaustive scan.  The
@@ -428,8 +428,16 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         const float y3 = y * y * y * 0.33333334f;
         const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;          // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
         const float dlo = (y >= 0.0f ? y - y3 : y) - 4e-6f;
-        wlo = j + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db)) - 1;
-        whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db)) + 1;
+        // No further slack: with D = beta_k - beta_j in [delta - alpha, delta + alpha] and every gap between
+        // neighbouring beams at least 1 / inv_db, a beam k > j has k - j <= D * inv_db, hence k <= j + floor(D *
+        // inv_db) <= whi; a computed product that falls short of the true one by a rounding (1e-7 relative, the
+        // factors above give 1e-6 and more) still rounds UP to that floor unless the true value is an integer
+        // to 1e-7 - and then it is the integer itself that ceilf returns.  Likewise below j.  (Until late in
+        // round 2 there was one more beam either side "for safety": 20 % more candidates; its removal is
+        // checked against the exhaustive search by tests/test_polar_window_bound.py on the CPU and by every
+        // GPU parity test.)
+        wlo = j + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db));
+        whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db));
         return small && whi - wlo < kPolarMax;
     };
     auto scan = [&](int a0, int a1, Best &b) {
