@@ -65,7 +65,7 @@ CONFIGS = {
     # name: scans, beams, grid, reso, room_scale, points, seed, lanes
     "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=4),
     "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=3),
-    "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=1),
+    "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=2),
 }
 
 
@@ -304,7 +304,10 @@ class ReplayWorkload:
 
 
 class ParticleWorkload:
-    """configs[2]: slam_particles_dev on P hypotheses; maps persist (no reset), live pmap."""
+    """configs[2]: slam_particles_dev on P hypotheses; maps persist (no reset), live pmap.  With several lanes
+    consecutive steps (independent: the same scan pair, the same priors) alternate between contexts that each
+    own a stream, output buffers and a set of P maps, so that one step's scan matching (vector-issue bound)
+    shares the chip with another's ray cast (memory bound)."""
     family_kernels = {"icp": "k_icp", "grid": "k_grid_update_owner", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
@@ -312,7 +315,6 @@ class ParticleWorkload:
         A = slam._abi
         self.dev = torch.device("cuda", local)
         torch.cuda.set_device(self.dev)
-        self.ctx = A.Context(local, torch.cuda.current_stream(self.dev).cuda_stream)
         P = self.P = args.particles
         self.rep = slam.synthetic.make_replay(2, args.beams, seed=2 + rank, stride=args.stride)
         n = args.beams
@@ -322,27 +324,42 @@ class ParticleWorkload:
         # the hypotheses differ by their prior perturbation only; every particle
         # starts the step at the same pose (tests/test_gpu_configs.py also runs scattered poses)
         self.pose_prev = np.zeros((P, 3))
-        self.t = dict(ranges2=d(self.rep.ranges.astype(np.float32)), cos_t=d(ct), sin_t=d(st), prior=d(self.mats.reshape(P, 6)),
-                      pose_prev=d(self.pose_prev), poses=torch.empty((P, 3), dtype=torch.float64, device=self.dev),
-                      T=torch.empty((P, 9), dtype=torch.float64, device=self.dev),
-                      iters=torch.empty(P, dtype=torch.int32, device=self.dev))
-        self.grid = slam.DeviceGrid.metric(P, args.grid, args.grid, args.reso, context=self.ctx)
-        self.pmap_ptr = self.grid.live_pmap()
+        self.shared = dict(ranges2=d(self.rep.ranges.astype(np.float32)), cos_t=d(ct), sin_t=d(st), prior=d(self.mats.reshape(P, 6)),
+                           pose_prev=d(self.pose_prev))
+
+        class Lane:
+            pass
+        self.lanes = []
+        for _ in range(max(1, n_lanes)):
+            ln = Lane()
+            ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
+            ln.ctx = A.Context(local, ln.stream.cuda_stream)
+            ln.t = dict(poses=torch.empty((P, 3), dtype=torch.float64, device=self.dev),
+                        T=torch.empty((P, 9), dtype=torch.float64, device=self.dev),
+                        iters=torch.empty(P, dtype=torch.int32, device=self.dev))
+            ln.grid = slam.DeviceGrid.metric(P, args.grid, args.grid, args.reso, context=ln.ctx)
+            ln.pmap_ptr = ln.grid.live_pmap()
+            ln.done = 0
+            self.lanes.append(ln)
+        self.ctx, self.t, self.grid = self.lanes[0].ctx, dict(self.shared, **self.lanes[0].t), self.lanes[0].grid
         self.ring = torch.empty((slots, 3), dtype=torch.float64, device=self.dev)
         self.L = A.lib()
         self.done = 0
         self.units_per_step = P
 
     def contexts(self):
-        return [self.ctx]
+        return [ln.ctx for ln in self.lanes]
 
     def step(self):
-        A, t, a = self.slam._abi, self.t, self.args
-        A.check(self.L.slam_particles_dev(self.ctx.handle, t["ranges2"].data_ptr(), t["cos_t"].data_ptr(), t["sin_t"].data_ptr(),
-                                          a.beams, A.DTYPES[a.points], t["prior"].data_ptr(), t["pose_prev"].data_ptr(), self.P,
-                                          a.max_iter, a.tol, self.grid._h, None, t["poses"].data_ptr(), t["T"].data_ptr(),
+        A, sh, a = self.slam._abi, self.shared, self.args
+        ln = self.lanes[self.done % len(self.lanes)]
+        t = ln.t
+        A.check(self.L.slam_particles_dev(ln.ctx.handle, sh["ranges2"].data_ptr(), sh["cos_t"].data_ptr(), sh["sin_t"].data_ptr(),
+                                          a.beams, A.DTYPES[a.points], sh["prior"].data_ptr(), sh["pose_prev"].data_ptr(), self.P,
+                                          a.max_iter, a.tol, ln.grid._h, None, t["poses"].data_ptr(), t["T"].data_ptr(),
                                           t["iters"].data_ptr()))
-        A.check(self.L.slam_grid_finalize_dev(self.ctx.handle, self.grid._h, self.pmap_ptr))
+        A.check(self.L.slam_grid_finalize_dev(ln.ctx.handle, ln.grid._h, ln.pmap_ptr))
+        ln.done += 1
         self.done += 1
         return None, self.done - 1
 
@@ -350,10 +367,11 @@ class ParticleWorkload:
         return self.t["poses"][-1].repeat(slots).contiguous()
 
     def collect(self):
-        self.ctx.check_status()
-        t = self.t
+        for ln in self.lanes:
+            ln.ctx.check_status()
+        t = self.lanes[0].t
         self.iters = t["iters"].cpu().numpy()
-        self.visits = self.grid.visits() / max(self.done, 1)     # per step (the maps are never reset)
+        self.visits = sum(ln.grid.visits() for ln in self.lanes) / max(self.done, 1)     # per step (the maps are never reset)
         return {"poses": t["poses"].cpu().numpy(), "T": t["T"].cpu().numpy(), "iters": self.iters}
 
     def parity(self, dev):
@@ -363,8 +381,8 @@ class ParticleWorkload:
         sample = sorted(set([0, P // 2, P - 1] + rng.integers(0, P, size=21).tolist()))
         out = checks.compare_particles(dev["poses"], dev["T"], dev["iters"], lambda p: self.grid.read(p, want=("pmap", "pass", "hit")),
                                        sample, self.rep.ranges[0], self.rep.ranges[1], AMIN, AMAX, self.mats, self.pose_prev,
-                                       a.grid, a.grid, a.reso, a.max_iter, a.tol, steps=self.done)
-        out["map_steps_accumulated"] = self.done
+                                       a.grid, a.grid, a.reso, a.max_iter, a.tol, steps=self.lanes[0].done)
+        out["map_steps_accumulated"] = self.lanes[0].done
         return out
 
     def algorithmic_bytes(self):
