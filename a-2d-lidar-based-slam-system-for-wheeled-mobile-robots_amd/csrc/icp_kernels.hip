@@ -392,7 +392,11 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 #ifndef SLAM_POLAR_MAX
 #define SLAM_POLAR_MAX 24
 #endif
-constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes
+constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes ...
+// ... in the launch shape that re-guesses useless first guesses (PROBE); the shapes without take windows four times
+// as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
+// lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
+constexpr int kPolarMaxLone = 96;
 constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
 constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
@@ -438,7 +442,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         // GPU parity test.)
         wlo = j + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db));
         whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db));
-        return small && whi - wlo < kPolarMax;
+        return small && whi - wlo < (PROBE ? kPolarMax : kPolarMaxLone);
     };
     auto scan = [&](int a0, int a1, Best &b) {
         // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
