@@ -1778,7 +1778,9 @@ template <class Src>
 static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s)
 {
     if (scans < 1) return hipSuccess;
-    int G = group > 0 ? group : 8;
+    // scans per (tile, group) workgroup: 16 by default (1080 beams, 2000 x 2000 cells, three overlapping replays:
+    // 8 -> 0.79, 12 -> 0.85, 16 -> 0.86, 24 -> 0.88, 32 -> 0.83 M scans/s; alone 16 equals 8 and 32 is 14 % slower)
+    int G = group > 0 ? group : 16;
     G = std::min(G, std::max(1, 65535 / n));
     G = std::min(G, scans);
     if (L > 1)                                    // a group is a contiguous range of ray ids: it must not straddle streams
