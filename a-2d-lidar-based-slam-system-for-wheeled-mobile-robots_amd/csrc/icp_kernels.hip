@@ -321,7 +321,10 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
         double2 ts = tarL[tslot(seed)];
         U = dist2(sx, sy, ts.x, ts.y);
     }
-    double bound = (U == U) ? U : INFINITY;      // a NaN seed distance bounds nothing
+    // (a block is marked if its box comes within the bound WIDENED by a class of equal distances: a point that
+    // ties with the guess for the reference - its square a last place above the guess's - may sit exactly on the
+    // edge of an otherwise farther box, and has to be seen for the tie to be noticed)
+    double bound = (U == U) ? U * (1.0 + 0x1p-49) : INFINITY;       // a NaN seed distance bounds nothing
     if (!active) bound = -1.0;                   // padding lanes never ask for a block
     Best b;
     b.start();
