@@ -1354,7 +1354,10 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     int groups = (scans + group - 1) / group;
     long rays = (long)group * n;
     long want = (rays + kRaysPerLane - 1) / kRaysPerLane;
-    int threads = want >= 1024 ? 1024 : (int)(((want + kWave - 1) / kWave) * kWave);
+#ifndef SLAM_WIN_MAX_THREADS
+#define SLAM_WIN_MAX_THREADS 1024
+#endif
+    int threads = want >= SLAM_WIN_MAX_THREADS ? SLAM_WIN_MAX_THREADS : (int)(((want + kWave - 1) / kWave) * kWave);
     if (threads < 128) threads = 128;
     // one workgroup per map and no other writer: single stream (L == 1) or one map per stream
     const int exclusive = g.pmap_live && groups == 1 && !got && (L == 1 || src.maps_are_private());

@@ -72,7 +72,7 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50; 10 for particles / dense)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 48; 12 for particles / dense)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="replay", choices=sorted(CONFIGS))
     ap.add_argument("--scans", type=int, default=None, help="processed scans per trajectory (default 1000; 5000 with --gpus > 1)")
@@ -111,7 +111,7 @@ def parse():
         # configs[3] (N > 1) names 5k-scan trajectories, configs[1] / [4] a 1k-scan replay
         args.scans = 5000 if (args.gpus > 1 and args.config == "replay") else cfg["scans"]
     if args.steps is None:
-        args.steps = 50 if args.config == "replay" else 10
+        args.steps = 48 if args.config == "replay" else 12     # (multiples of the lane counts 4 / 2 / 3: no lane runs a step more than another)
     if args.warmup is None:
         args.warmup = 5 if args.config == "replay" else 2
     if args.grid_group < 0:
