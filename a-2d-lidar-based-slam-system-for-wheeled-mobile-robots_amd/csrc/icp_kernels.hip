@@ -393,14 +393,17 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // apply (closer to the origin than 2 sqrt(U), NaN) are left to the box search (`big`).
 // ---------------------------------------------------------------------------------
 #ifndef SLAM_POLAR_MAX
-#define SLAM_POLAR_MAX 24
+#define SLAM_POLAR_MAX 32
 #endif
 constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes ...
 // ... in the launch shape that re-guesses useless first guesses (PROBE); the shapes without take windows four times
 // as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
 // lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
 constexpr int kPolarMaxLone = 96;
-constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
+#ifndef SLAM_POLAR_PROBE
+#define SLAM_POLAR_PROBE 8
+#endif
+constexpr int kPolarProbe = SLAM_POLAR_PROBE;                // beams either side of a useless guess that are tried for a better one
 constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
 template <typename T> struct StoreSlack { static constexpr float ang = 2e-7f; };              // float64 points
