@@ -338,12 +338,19 @@ struct ReplaySource {
         sc.pcx = to_cell(ox, g.scale, g.off_x, sc.cbad);
         sc.pcy = to_cell(oy, g.scale, g.off_y, sc.cbad);
     }
-    // false: beam skipped (mapping.py:30) or flagged in `bad`
-    __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    // a beam's inputs (fetch) and its end cell (ray) are separate so that a kernel can have the loads in
+    // flight while it does something else
+    struct Beam { float r; double ct, st; };
+    __device__ Beam fetch(int l, int k, int i) const
     {
-        double rr = (double)ranges[(size_t)l * traj_stride + (size_t)(k + 1) * n + i];
+        return Beam{ranges[(size_t)l * traj_stride + (size_t)(k + 1) * n + i], cos_t[i], sin_t[i]};
+    }
+    // false: beam skipped (mapping.py:30) or flagged in `bad`
+    __device__ bool ray(const Beam &b, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    {
+        double rr = (double)b.r;
         if (rr == INFINITY) rr = 30.0;                               // slam_ekf.py:119
-        double lx = cos_t[i] * rr, ly = sin_t[i] * rr;               // :122
+        double lx = b.ct * rr, ly = b.st * rr;                       // :122
         double x = sc.c * lx + (-sc.s) * ly + sc.px * 1.0;           // u2T(pose).dot(pc), :89
         double y = sc.s * lx + sc.c * ly + sc.py * 1.0;
         if (fabs(x) == INFINITY) return false;
@@ -351,6 +358,10 @@ struct ReplaySource {
         poy = to_cell(y, g.scale, g.off_y, bad);
         bad |= sc.cbad;
         return !bad;
+    }
+    __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    {
+        return ray(fetch(l, k, i), sc, g, pox, poy, bad);
     }
 };
 
@@ -368,14 +379,19 @@ struct ExplicitSource {
         sc.pcx = to_cell(sc.px, g.scale, g.off_x, sc.cbad);
         sc.pcy = to_cell(sc.py, g.scale, g.off_y, sc.cbad);
     }
-    __device__ bool ray(int, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    struct Beam { double x, y; };
+    __device__ Beam fetch(int, int k, int i) const { return Beam{ox[(size_t)k * n + i], oy[(size_t)k * n + i]}; }
+    __device__ bool ray(const Beam &b, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
     {
-        double x = ox[(size_t)k * n + i], y = oy[(size_t)k * n + i];
-        if (fabs(x) == INFINITY) return false;                       // mapping.py:30
-        pox = to_cell(x, g.scale, g.off_x, bad);
-        poy = to_cell(y, g.scale, g.off_y, bad);
+        if (fabs(b.x) == INFINITY) return false;                     // mapping.py:30
+        pox = to_cell(b.x, g.scale, g.off_x, bad);
+        poy = to_cell(b.y, g.scale, g.off_y, bad);
         bad |= sc.cbad;
         return !bad;
+    }
+    __device__ bool ray(int l, int k, int i, const ScanConst &sc, const GridDev &g, int &pox, int &poy, int &bad) const
+    {
+        return ray(fetch(l, k, i), sc, g, pox, poy, bad);
     }
 };
 
@@ -1023,7 +1039,7 @@ struct OwnRay {
 };
 
 template <class Src, int kOwnerRays>
-__global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, Src src, int sort_cap, int win_cells)
+__device__ __forceinline__ void owner_cast(const GridDev &g, const Src &src, int sort_cap, int win_cells, const int l)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);
@@ -1036,7 +1052,7 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     STAMP_DECL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = blockIdx.y, gi = src.own_grid(l), n = src.n;
+    const int gi = src.own_grid(l), n = src.n;
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
     int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
     unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
@@ -1338,6 +1354,361 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner(GridDev g, 
     lds_guard_check(guard, g.status);
 }
 
+// The general owner kernel has two launch forms: one workgroup per map (blockIdx.y), or - behind the
+// byte-window kernel below - a fixed number of workgroups that work off the list of maps that kernel
+// left for it (redo[0]: count, redo[1]: workgroups done, redo[2..]: map numbers; normally empty).
+template <class Src, int kOwnerRays>
+__global__ void __launch_bounds__(kOwnerThreads, kOwnerRays == 1 ? 2 * kOwnerThreads / 256 : kOwnerThreads / 256)
+k_grid_update_owner(GridDev g, Src src, int sort_cap, int win_cells)
+{
+    owner_cast<Src, kOwnerRays>(g, src, sort_cap, win_cells, (int)blockIdx.y);
+}
+
+template <class Src, int kOwnerRays>
+__global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner_redo(GridDev g, Src src, int sort_cap, int win_cells, int32_t *redo)
+{
+    const int count = redo[0];
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        owner_cast<Src, kOwnerRays>(g, src, sort_cap, win_cells, redo[2 + it]);
+        __syncthreads();                                             // the next map re-uses the LDS regions
+    }
+    // every workgroup has read the count before it reports here: the last one empties the list for the next launch
+    if (threadIdx.x == 0 && atomicAdd(&redo[1], 1) == (int)gridDim.x - 1) { redo[0] = 0; redo[1] = 0; }
+}
+
+// ---------------------------------------------------------------------------------
+// Single-scan owner kernel with a BYTE window (DESIGN.md "K4 owner8"): the plain case of the kernel above -
+// every beam valid, every ray inside the map, at most one ray per lane - with 8-bit window cells, so that the
+// whole bounding box of a scan (236 x 212 cells for the 10 m x 8 m benchmark room at 0.05 m) is ONE window of
+// ~50 KB and three workgroups share a CU.  One phase per map: no strips, no direction halves, every ray walked
+// once without bounds tests, one sweep.
+//   * a window byte = 7-bit pass count + bit 7 "a hit fell here".  The scan's origin cell is the first cell of
+//     every path and would count all n rays: it is left out of the walk and its count (the number of non-empty
+//     rays) is added by the sweep.  Any other cell sees only the rays whose direction lies within a cell's width
+//     of it: 54 of 360 next to the origin on the benchmark scan.
+//   * nothing bounds a byte for arbitrary input (n identical rays), and a count of 128 would spill into the flag
+//     and the neighbouring cell.  So the walk is CHECKED before anything is written to the map: the sum of all
+//     window bytes (flags masked) must equal the number of cells the rays passed, which the set-up knows
+//     (sum of dx - 1).  Every overflow event lowers the masked byte sum (by 128, 127 or 126 ...) and nothing
+//     raises it, so equality proves that no byte overflowed.  On a mismatch - and for every case this kernel
+//     does not handle: a bad beam, a ray leaving the map, a box larger than the window - the map's number goes
+//     on the re-do list and the general kernel above casts it; this kernel has then written nothing to it.
+//   * set-up with two barriers: the beam loads are in flight while LDS is initialised; the counting sort by
+//     length (longest rays in the lowest waves) takes the rank inside a bin from the histogram atomic's return
+//     value and the bin's offset from a wave-level scan that every wave does for itself; the sorted end cells
+//     travel through LDS as packed 16-bit pairs instead of being loaded and computed a second time.
+//   * the sweep keeps BATCH 16-byte read-modify-writes per lane in flight; counters and pmap rule exactly as in
+//     the kernel above (mapping.py:42-50).
+// ---------------------------------------------------------------------------------
+constexpr int kOwn8Bins = 128;
+constexpr int kOwn8BoxInts = 16;
+constexpr int kOwn8MaxLen = 2048;
+#ifndef SLAM_X8
+#define SLAM_X8 0
+#endif
+#ifndef SLAM_OWN8_THREADS
+#define SLAM_OWN8_THREADS 384
+#endif
+#ifndef SLAM_OWN8_BATCH
+#define SLAM_OWN8_BATCH 8
+#endif
+#ifndef SLAM_OWN8_PIECES
+#define SLAM_OWN8_PIECES 0
+#endif
+#ifndef SLAM_OWN8_LDS
+#define SLAM_OWN8_LDS 53760
+#endif
+constexpr int kOwn8Threads = SLAM_OWN8_THREADS;   // >= kOwn8Bins, a multiple of 64
+constexpr int kOwn8Batch = SLAM_OWN8_BATCH;
+constexpr bool kOwn8Pieces = SLAM_OWN8_PIECES != 0;
+// LDS of a workgroup: 42 allocation granules of 1 280 bytes, so that three workgroups fit a CU's 160 KiB
+constexpr int kOwn8LdsBytes = SLAM_OWN8_LDS;
+constexpr int kOwn8PerCU = 163840 / kOwn8LdsBytes;      // workgroups per CU the register budget is set for
+__host__ __device__ inline size_t own8_fixed_bytes(int threads) { return (size_t)(kOwn8BoxInts + kOwn8Bins) * 4 + (size_t)threads * 4; }
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kBufferRsrcWord3 = 0x00020000;     // raw buffer, 32-bit data format (gfx9 / CDNA)
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ void lds_or_u32(unsigned addr, unsigned v)
+{
+    (void)__hip_atomic_fetch_or((lds_u32_t *)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class Src, int THREADS, int BATCH, bool PIECES>
+__global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k_grid_update_owner8(GridDev g, Src src, int win_bytes, int32_t *__restrict__ redo)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *box = reinterpret_cast<int *>(smem);                        // [0..3] bounding box, [4] odd case seen, [5] cells the rays pass, [6] window byte sum
+    int *hist = box + kOwn8BoxInts;                                  // [kOwn8Bins] rays per length bin
+    unsigned *slots = reinterpret_cast<unsigned *>(hist + kOwn8Bins);   // [THREADS] end cells in sorted order
+    unsigned *win = slots + THREADS;                                 // [W][Hs] bytes
+    char *guard = reinterpret_cast<char *>(win) + win_bytes;
+    lds_guard_fill(guard);
+    STAMP_DECL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l = blockIdx.y, gi = src.own_grid(l), n = src.n;
+    auto give_up = [&]() {                                           // (uniform) leave the map to the general kernel
+        if (tid == 0) redo[2 + atomicAdd(&redo[0], 1)] = l;
+    };
+
+#if SLAM_X8 & 64
+    return;
+#endif
+#ifdef SLAM_OWN8_STAGGER
+    if (blockIdx.y < 768u) {                                          // experiment: random start phases for the first generation
+        const int slices = (int)((blockIdx.y * 2654435761u) >> 28);  // 0..15
+        for (int k = 0; k < slices * SLAM_OWN8_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles = 3.4 us each
+    }
+#endif
+    // this lane's beam: loads first, LDS set-up while they are in flight
+    typename Src::Beam beam = src.fetch(l, 0, tid < n ? tid : 0);
+    ScanConst c0;
+    src.scan_const(l, 0, g, c0);
+    if (tid < kOwn8BoxInts) box[tid] = tid < 2 ? INT_MAX : (tid < 4 ? INT_MIN : 0);
+    if (tid < kOwn8Bins) hist[tid] = 0;
+    {
+        uint4 *w4 = reinterpret_cast<uint4 *>(win);
+        for (int w = tid; w < (win_bytes >> 4); w += THREADS) w4[w] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    STAMP(0);
+#if SLAM_X8 & 128
+    if (c0.px != 1234.5) return;
+#endif
+
+    // pass 1: end cell, length bin, bounding box (mapping.py:30-36)
+    int pox = 0, poy = 0, b2 = 0;
+    const bool ok = tid < n && src.ray(beam, c0, g, pox, poy, b2);
+    const bool inmap = (unsigned)c0.pcx < (unsigned)g.xw && (unsigned)c0.pcy < (unsigned)g.yw &&
+                       (unsigned)pox < (unsigned)g.xw && (unsigned)poy < (unsigned)g.yw;
+    // int() would raise / the ray leaves the map / a ray longer than the lengths for which "the float walk ends
+    // in the cell of its other end" has been checked exhaustively (dx <= 2100: tests/test_walk_ends.py)
+    const int len = max(abs(pox - c0.pcx), abs(poy - c0.pcy));
+    const bool odd = (tid < n && b2 != 0) || (ok && (!inmap || len > kOwn8MaxLen));
+    const bool valid = ok && inmap && len > 0 && len <= kOwn8MaxLen;   // identical cells: empty path (bresenham.py:10-11)
+    int bin = 0, idx = 0;
+    if (valid) {
+        bin = kOwn8Bins - 1 - min(len >> 2, kOwn8Bins - 1);          // longest first
+        idx = atomicAdd(&hist[bin], 1);
+    }
+    const unsigned pk = (unsigned)pox | ((unsigned)poy << 16);       // (both < 65 536 when valid)
+    {
+        unsigned lo = valid ? pk : 0xffffffffu, hi = valid ? pk : 0u;
+        int cells = valid ? len - 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = pk_min_u16(lo, (unsigned)__shfl_xor((int)lo, off, kWave));
+            hi = pk_max_u16(hi, (unsigned)__shfl_xor((int)hi, off, kWave));
+            cells += __shfl_xor(cells, off, kWave);
+        }
+        const unsigned long long anyv = __ballot(valid), anyodd = __ballot(odd);
+        if (lane == 0) {
+            if (anyv) {
+                atomicMin(&box[0], (int)(lo & 0xffffu)); atomicMin(&box[1], (int)(lo >> 16));
+                atomicMax(&box[2], (int)(hi & 0xffffu)); atomicMax(&box[3], (int)(hi >> 16));
+                atomicAdd(&box[5], cells);
+            }
+            if (anyodd) box[4] = 1;
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    if (box[4]) { give_up(); return; }
+    // counting sort: every wave scans the histogram for itself (two bins per lane)
+    const int h0 = hist[2 * lane], h1 = hist[2 * lane + 1];
+    int inc = h0 + h1;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { const int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
+    const int nv = __shfl(inc, kWave - 1, kWave);                    // non-empty rays
+    if (nv == 0) return;                                             // nothing to cast (mapping.py:38-39: empty paths)
+    const int x0 = min(box[0], c0.pcx), y0 = min(box[1], c0.pcy), x1 = max(box[2], c0.pcx), y1 = max(box[3], c0.pcy);
+    const int y4 = y0 & ~3, Hs = ((y1 | 3) + 1) - y4, W = x1 - x0 + 1;   // window rows of whole quads (4 cells = 16 counter bytes)
+    if ((long)W * Hs > (long)win_bytes) { give_up(); return; }
+    {
+        const int excl = inc - (h0 + h1);
+        int base = __shfl(excl, bin >> 1, kWave);
+        const int first = __shfl(h0, bin >> 1, kWave);
+        if (bin & 1) base += first;
+        if (valid) slots[base + idx] = pk;
+    }
+    __syncthreads();
+    STAMP(2);
+#if SLAM_X8 & 256
+    return;
+#endif
+
+    // this lane's ray: the tid-th longest
+    const bool have = tid < nv;
+    const unsigned e = have ? slots[tid] : 0u;
+    const int ex = (int)(e & 0xffffu), ey = (int)(e >> 16);
+    Ray rr;
+    rr.x0 = rr.y0 = 0; rr.dx = 1; rr.ystep = 1; rr.derr = 0.0; rr.steep = rr.flag = false;
+    if (have) (void)ray_setup(c0.pcx, c0.pcy, ex, ey, rr);
+    const unsigned wbase = lds_addr(win);
+    if (have) {                                                      // the path's last cell is the end cell: the hit (mapping.py:44-45)
+        const unsigned b = (unsigned)((ex - x0) * Hs + (ey - y4));
+        lds_or_u32(wbase + (b & ~3u), 0x80u << ((b & 3u) * 8u));
+    }
+    {
+        // the walk (bresenham.py:45-55) without its two end steps: walk step 0 is the origin cell (or, for a
+        // reversed path, the hit cell) and step dx the hit cell (or the origin): dx - 1 cells in between
+        const int lx = rr.steep ? rr.y0 : rr.x0, ly = rr.steep ? rr.x0 : rr.y0;
+        unsigned a = wbase + (unsigned)((lx - x0) * Hs + (ly - y4));
+        const int da_k = rr.steep ? 1 : Hs, da_y = rr.steep ? rr.ystep * Hs : rr.ystep;
+        double error = 0.0;                                          // bresenham.py:34
+        int rem = have ? rr.dx - 1 : 0;
+#if SLAM_X8 & 16
+        rem = 0; box[5] = 0;
+#endif
+        auto advance = [&]() {
+            error += rr.derr;                                        // :51
+            const bool stepy = error >= 0.5;                         // :53
+            a += (unsigned)(da_k + (stepy ? da_y : 0));
+            error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);    // :55 (minus 1.0, or minus 0.0: exact)
+        };
+        auto step = [&]() {
+            lds_add_u32(a & ~3u, 1u << ((a << 3) & 31u));            // mapping.py:43
+            advance();
+        };
+        if (have) advance();
+        for (;;) {                                                   // four steps per wave-wide test, no lane mask inside
+            const bool full = rem >= 4;
+            if (!__any(full)) break;
+            if (full) { step(); step(); step(); step(); rem -= 4; }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (rem > u) step();
+    }
+    __syncthreads();
+    STAMP(3);
+#if SLAM_X8 & 512
+    return;
+#endif
+
+    // From here on a wave works on whole window rows (map x = x0 + r), 64 quads of a row at a time (a quad: 4 cells,
+    // one window dword, 16 bytes of counters, 4 of pmap): row and segment are wave-uniform, so the window index and the
+    // map addresses are a scalar base plus a per-lane constant and cost no vector instruction.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = THREADS / kWave;
+    const int qrow = Hs >> 2, nseg = (qrow + kWave - 1) >> 6;
+
+    // the check: masked byte sum of the window == cells the rays passed
+    {
+        unsigned acc = 0u;
+        for (int seg = 0; seg < nseg; ++seg) {
+            const int c = seg * kWave + lane;
+            if (c < qrow)
+                for (int r = wv; r < W; r += NW) acc = __builtin_amdgcn_sad_u8(win[r * qrow + c] & 0x7f7f7f7fu, 0u, acc);
+        }
+        acc = wave_sum_u32(acc);
+        if (lane == 0 && acc) atomicAdd(&box[6], (int)acc);
+    }
+    __syncthreads();
+    if (box[6] != box[5]) { give_up(); return; }
+#if SLAM_X8 & 1024
+    return;
+#endif
+
+    uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
+    int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
+    if (tid == 0) atomicAdd(visit_slot(g.visits), (unsigned long long)(box[5] + 2 * nv));   // every cell of every path is in the map (:41)
+
+    // sweep.  Counters and pmap go through buffer loads / stores: the map's row is the scalar offset, the lane's quad
+    // the vector offset, and a lane with nothing to do gets an offset beyond the buffer - the hardware then neither
+    // reads nor writes for it - so a batch of rows is straight-line code without branches or lane masks.
+    const uint32_t pthr = g.pass_thresh[0];
+    const int org_r = c0.pcx - x0, org_q = (c0.pcy - y4) >> 2;       // the origin cell's row, quad ...
+    const unsigned org_b = (unsigned)(c0.pcy - y4) & 3u;             // ... and byte in the quad
+    const __amdgpu_buffer_rsrc_t rs_pass = __builtin_amdgcn_make_buffer_rsrc(pass, 0, g.xw * g.yw * 4, kBufferRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rs_pm = __builtin_amdgcn_make_buffer_rsrc(pm, 0, g.xw * g.yw, kBufferRsrcWord3);
+    constexpr unsigned kSkip = 0x80000000u;                          // (beyond any map: xw * yw * 4 < 2^31, checked by the launcher)
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int c = seg * kWave + lane;
+        const bool incol = c < qrow;
+        const bool org_lane = c == org_q;
+        for (int r0 = wv; r0 < W; r0 += NW * BATCH) {
+            u32x4_t p[BATCH];
+            uint32_t om[BATCH], dd[BATCH], vo[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = r0 + u * NW;                           // (wave-uniform)
+                const int rc = min(r, W - 1);
+                const uint32_t rowoff = (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
+                dd[u] = (incol && r < W) ? win[rc * qrow + c] : 0u;
+                const bool live = dd[u] != 0u || (r == org_r && org_lane);
+                vo[u] = live ? (unsigned)lane << 4 : kSkip;         // byte offset of the lane's quad in the counter row
+#if SLAM_X8 & 4
+                p[u] = u32x4_t{rowoff, rowoff, rowoff, rowoff};
+#else
+                p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff << 2, 0);
+#endif
+#if SLAM_X8 & 1
+                om[u] = 0x32323232u;
+#else
+                om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vo[u] >> 2, rowoff, 0);
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = r0 + u * NW;
+                const int rc = min(r, W - 1);
+                const uint32_t rowoff = (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
+                const uint32_t d = dd[u], dm = d & 0x7f7f7f7fu;
+                u32x4_t q = p[u];
+                q.x += dm & 0xffu; q.y += (dm >> 8) & 0xffu; q.z += (dm >> 16) & 0xffu; q.w += dm >> 24;   // mapping.py:43
+                // one bit per cell (bit 7 of its byte): passed or hit by this scan
+                uint32_t t7 = ((dm + 0x7f7f7f7fu) | d) & 0x80808080u;
+                if (r == org_r) {                                    // (wave-uniform) every non-empty path starts in the origin cell
+                    if (org_lane) {
+                        q.x += org_b == 0u ? (uint32_t)nv : 0u; q.y += org_b == 1u ? (uint32_t)nv : 0u;
+                        q.z += org_b == 2u ? (uint32_t)nv : 0u; q.w += org_b == 3u ? (uint32_t)nv : 0u;
+                        t7 |= 0x80u << (8u * org_b);
+                    }
+                }
+#if !(SLAM_X8 & 2)
+                __builtin_amdgcn_raw_buffer_store_b128(q, rs_pass, vo[u], rowoff << 2, 0);
+#endif
+                // pmap (mapping.py:47-50): a touched cell shows 0 or 100 afterwards.  Its byte changes iff it was never
+                // touched before (50: bit 4 is set in 50 only), or it is hit now and was not occupied (bit 6 is set in
+                // 100 only), or its pass count is at or over the threshold now
+                const uint32_t o = om[u];
+                const uint32_t need = ((t7 >> 3) & o & 0x10101010u) | (d & ~(o << 1) & 0x80808080u);
+                const uint32_t pmax = max(max(q.x, q.y), max(q.z, q.w));
+                if ((need != 0u || pmax >= pthr) && vo[u] != kSkip) {
+                    const uint32_t tb = t7 >> 7, fb = (d >> 7) & 0x01010101u, was = (o >> 6) & 0x01010101u;
+                    uint32_t occ = was | fb;
+                    occ |= (q.x >= pthr ? 1u : 0u) | (q.y >= pthr ? 0x100u : 0u) | (q.z >= pthr ? 0x10000u : 0u) | (q.w >= pthr ? 0x1000000u : 0u);
+                    const uint32_t tm = tb * 255u;
+                    const uint32_t out = (o & ~tm) | ((occ * 100u) & tm);
+#if !(SLAM_X8 & 32)
+                    if (out != o) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vo[u] >> 2, rowoff, 0);
+#endif
+                }
+            }
+        }
+    }
+    // the hits last (mapping.py:45): fire-and-forget atomics, which the sweep's loads would otherwise queue behind
+#if !(SLAM_X8 & 8)
+    if (have) atomicAdd(&hit[(size_t)ex * g.yw + ey], 1u);
+#endif
+#ifdef SLAM_STAMPS
+    __syncthreads();
+#endif
+    STAMP(4);
+    STAMP_END(5);
+    lds_guard_check(guard, g.status);
+}
+
 template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s)
@@ -1372,26 +1743,32 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     if (threads < SLAM_WIN_MIN_THREADS) threads = SLAM_WIN_MIN_THREADS;
     const int sort_cap = win_sort_cap((long)group * n);
     const int win_cells = win_cells_for(group, sort_cap);
-#ifndef SLAM_NO_OWNER_KERNEL
     // one scan per map, cast by the map's only writer, live pmap, the reference's one-hit-occupies rule
     if (exclusive && group == 1 && scans == 1 && g.hit_levels == 1 && (g.yw & 15) == 0 && (((size_t)g.xw * g.yw) & 3) == 0 &&
         g.yw <= win_cells && n <= kOwnerMaxRays * kOwnerThreads) {
         static bool own_attr[2] = {false, false};
         if (!own_attr[which]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_owner<Src, 1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_owner<Src, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-            if (e != hipSuccess) return e;
+            for (const void *f : {reinterpret_cast<const void *>(&k_grid_update_owner<Src, 1>), reinterpret_cast<const void *>(&k_grid_update_owner<Src, 2>),
+                                  reinterpret_cast<const void *>(&k_grid_update_owner_redo<Src, 1>)}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+                if (e != hipSuccess) return e;
+            }
             own_attr[which] = true;
         }
         const size_t lds = win_lds_bytes(1, sort_cap, win_cells);
+        // the plain case (all of a closed room's scans) goes through the byte-window kernel, three workgroups per CU;
+        // whatever it leaves on the re-do list is cast by the general kernel behind it
+        if (g.redo && n <= kOwn8Threads && n <= kOwnerThreads && g.xw <= 65535 && g.yw <= 65535 && (long)g.xw * g.yw < (1L << 29)) {
+            const int own8_lds = kOwn8LdsBytes + kLdsGuard, own8_win = (int)(kOwn8LdsBytes - own8_fixed_bytes(kOwn8Threads));
+            SLAM_LAUNCH((k_grid_update_owner8<Src, kOwn8Threads, kOwn8Batch, kOwn8Pieces>), dim3(1, L), dim3(kOwn8Threads), own8_lds, s,
+                        g, src, own8_win, g.redo);
+            SLAM_LAUNCH((k_grid_update_owner_redo<Src, 1>), dim3(std::min(L, 512)), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells, g.redo);
+            return hipGetLastError();
+        }
         if (n <= kOwnerThreads) SLAM_LAUNCH((k_grid_update_owner<Src, 1>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
         else                    SLAM_LAUNCH((k_grid_update_owner<Src, 2>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
         return hipGetLastError();
     }
-#endif
     SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
                 exclusive, sort_cap, win_cells);
     return hipGetLastError();
@@ -1799,9 +2176,9 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
     ts.gbox = reinterpret_cast<int *>(p);
     if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
     // the family is three launches: bracket it with recorded events when timing is armed
-    LaunchEvents ev = g_launch_ev;
-    g_launch_ev = {nullptr, nullptr};
-    if (ev.e0) (void)hipEventRecord(ev.e0, s);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool timed = launch_events(&ev0, &ev1);
+    if (timed) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(k_tile_init, dim3((groups + 255) / 256), dim3(256), 0, s, ts.gbox, (int)groups);
     hipLaunchKernelGGL((k_ray_bits<Src>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
     const int tiles_x = (g.xw + kTileSide - 1) / kTileSide, tiles_y = (g.yw + kTileSide - 1) / kTileSide;
@@ -1816,7 +2193,7 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
     // 1024 lanes: the kernel is bound by the latency of its loads and LDS atomics (measured 2.35 ms
     // with 512, 2.14 ms with 1024 on the 1080-beam / 2000x2000 replay; tiles of 128 or 224 cells are slower)
     hipLaunchKernelGGL(k_tile_cast, dim3(tiles_x * tiles_y, (unsigned)groups), dim3(1024), lds, s, g, ts, tiles_x, G * n, rays);
-    if (ev.e1) (void)hipEventRecord(ev.e1, s);
+    if (timed) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }
 

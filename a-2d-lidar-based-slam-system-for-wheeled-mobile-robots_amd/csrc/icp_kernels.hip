@@ -446,8 +446,10 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         // round 2 there was one more beam either side "for safety": 20 % more candidates; its removal is
         // checked against the exhaustive search by tests/test_polar_window_bound.py on the CPU and by every
         // GPU parity test.)
-        wlo = j + (int)floorf(fminf(0.0f, (dlo - alpha) * geo.inv_db));
-        whi = j + (int)ceilf(fmaxf(0.0f, (dhi + alpha) * geo.inv_db));
+        // (clamped to one turn either side: a window that wide is refused below, and the sums cannot wrap)
+        const float fn = (float)n_tar;
+        wlo = j + (int)floorf(fmaxf(-fn, fminf(0.0f, (dlo - alpha) * geo.inv_db)));
+        whi = j + (int)ceilf(fminf(fn, fmaxf(0.0f, (dhi + alpha) * geo.inv_db)));
         return small && whi - wlo < (PROBE ? kPolarMax : kPolarMaxLone);
     };
     auto scan = [&](int a0, int a1, Best &b) {
@@ -728,11 +730,15 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
     Box *boxes4 = boxes + nn_boxes_padded(a.n_tar);                                              // one per 4 blocks
-    double2 *tarP = reinterpret_cast<double2 *>(smem + nn_lds_bytes(a.n_tar));                   // [n_tar + kPolarTail]: the target again, not padded (nn_polar)
-    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar));   // [2][kMaxWaves][8]
+    // the target again, not padded, for the beam-window search (nn_polar): carved when the target is a scan and
+    // both copies fit the CU's LDS (launch_icp_t); without it the padded copy serves every purpose
+    const bool has_p = a.polar_copy != 0;
+    const size_t p_bytes = has_p ? icp_polar_bytes(a.n_tar) : 0;
+    double2 *tarP = has_p ? reinterpret_cast<double2 *>(smem + nn_lds_bytes(a.n_tar)) : nullptr;   // [n_tar + kPolarTail]
+    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + p_bytes);             // [2][kMaxWaves][8]
     unsigned *geo = reinterpret_cast<unsigned *>(red + kIcpRedDoubles);                          // [4] polar_probe; geo[3]: source set collapsed
     double *cref = reinterpret_cast<double *>(geo + 4);                                          // [2][4]: matched point of query 0, "all the same" flag
-    char *guard = smem + nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
+    char *guard = smem + nn_lds_bytes(a.n_tar) + p_bytes + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
     lds_guard_fill(guard);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -755,7 +761,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     stage_boxes(n_tar, tarL, boxes, boxes4);
     ISTAMP(11);
 #ifndef SLAM_NO_POLAR
-    if (a.ranges) polar_probe(tar, n_tar, geo);
+    if (a.ranges && has_p) polar_probe(tar, n_tar, geo);
 #endif
     ISTAMP(12);
 
@@ -800,7 +806,9 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     PolarGeo pg;
     {
         const float dmin = __uint_as_float(geo[0]), span = __uint_as_float(geo[2]);
-        const bool polar = geo[1] != 0u && n_tar >= 2 && dmin > 0.0f && dmin < 1.0f && span <= 6.2831855f + 0.5f * dmin;
+        // (beams closer together than 1e-5 rad are no usable geometry: the window's index bound (dhi + alpha) * inv_db
+        // must stay far inside the int range)
+        const bool polar = has_p && geo[1] != 0u && n_tar >= 2 && dmin >= 1e-5f && dmin < 1.0f && span <= 6.2831855f + 0.5f * dmin;
         pg.inv_db = polar ? __fdividef(1.000002f, dmin) : 0.0f;
         pg.slack = StoreSlack<T>::ang;
     }
@@ -819,7 +827,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
             double d2; int j;
             bool amb = false;
             if (EXACT) {
-                const NNHit h = nn_exact(tarP, false, ok[q] ? n_tar : 0, sx[q], sy[q]);
+                const NNHit h = nn_exact(has_p ? tarP : tarL, !has_p, ok[q] ? n_tar : 0, sx[q], sy[q]);
                 d2 = h.d2; j = h.j;
             } else if (pg.inv_db > 0.0f) {                           // wave-uniform: the target is a scan
                 bool big;
@@ -842,7 +850,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
             }
             amb_any |= amb;                                          // -> a.redo[b]: the EXACT launch re-does this pair
             seed[q] = j;                                             // next iteration's guess
-            double2 m = tarP[j];
+            double2 m = has_p ? tarP[j] : tarL[tslot(j)];
             mx[q] = m.x; my[q] = m.y;
             double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
             if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dist; }
@@ -942,8 +950,9 @@ static inline int icp_block(int n_src, int qpt)
 }
 
 template <typename T>
-static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
+static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
 {
+    IcpArgs a = a_in;
     int qpt = (a.n_src + 1023) / 1024;
     // Queries per lane for batches (a handful of pairs cannot fill the chip anyway: one query per lane
     // gives the lowest latency, 0.13 instead of 0.15 ms for the drop-in ICP.process call).  Fewer waves per
@@ -953,7 +962,11 @@ static hipError_t launch_icp_t(const IcpArgs &a, hipStream_t s)
     // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
     int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
     if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
-    size_t lds = nn_lds_bytes(a.n_tar) + icp_polar_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
+    const size_t lds_base = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
+    // second, unpadded copy of the target for the beam-window search: only for scans, and only while both copies fit
+    // (up to 4 544 beams; larger scans, up to the documented 8 192, and point clouds go by the box search alone)
+    a.polar_copy = (a.ranges && lds_base + icp_polar_bytes(a.n_tar) <= 160 * 1024) ? 1 : 0;
+    size_t lds = lds_base + (a.polar_copy ? icp_polar_bytes(a.n_tar) : 0);
 #ifdef SLAM_ICP_LDS_PAD
     if (a.B > 64) lds += SLAM_ICP_LDS_PAD;      // tuning experiments: fewer resident workgroups per CU
 #endif

@@ -61,6 +61,7 @@ struct Arena {
 struct Pending {
     int kind;
     hipEvent_t e0, e1;
+    bool first;      // first launch of its timing bracket: the family's launch count goes by brackets
 };
 
 }  // namespace
@@ -110,7 +111,7 @@ struct slam_grid {
     bool live_dirty = false;       // pmap_live is behind the counters
 };
 
-namespace slam { thread_local LaunchEvents g_launch_ev = {nullptr, nullptr}; }
+namespace slam { thread_local LaunchTimer g_launch_timer = {nullptr, nullptr}; }
 
 namespace {
 
@@ -157,28 +158,31 @@ int redo_flags(slam_ctx *c, long B, int32_t **out)
     return SLAM_OK;
 }
 
-// RAII bracket around one kernel launch of a family: arms the events the launch will carry.
+// RAII bracket around the kernel launch(es) of a family: every SLAM_LAUNCH inside it draws a
+// fresh pair of events from it (slam_internal.h), and the family's time is the sum of its launches.
 struct Timed {
     slam_ctx *c;
     int kind;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    Timed(slam_ctx *ctx, int k, hipStream_t = nullptr) : c(ctx), kind(k)
+    LaunchTimer saved;
+    bool used = false;
+    Timed(slam_ctx *ctx, int k, hipStream_t = nullptr) : c(ctx), kind(k), saved(g_launch_timer)
     {
-        if (!c->timing) return;
-        e0 = get();
-        e1 = get();
-        if (e0 && e1) g_launch_ev = {e0, e1};
+        if (c->timing) g_launch_timer = {this, &Timed::next};
     }
-    ~Timed()
+    ~Timed() { g_launch_timer = saved; }
+    static bool next(void *self, hipEvent_t *e0, hipEvent_t *e1)
     {
-        if (!c->timing || !e0 || !e1) return;
-        if (g_launch_ev.e0 == e0) {              // nothing was launched inside the bracket
-            g_launch_ev = {nullptr, nullptr};
-            c->pool.push_back(e0);
-            c->pool.push_back(e1);
-            return;
+        Timed *t = static_cast<Timed *>(self);
+        *e0 = t->get();
+        *e1 = t->get();
+        if (!*e0 || !*e1) {
+            if (*e0) t->c->pool.push_back(*e0);
+            if (*e1) t->c->pool.push_back(*e1);
+            return false;
         }
-        c->pending.push_back({kind, e0, e1});
+        t->c->pending.push_back({t->kind, *e0, *e1, !t->used});
+        t->used = true;
+        return true;
     }
     hipEvent_t get()
     {
@@ -468,7 +472,7 @@ int slam_timing_read(slam_ctx *c, double ms_out[SLAM_K_COUNT], int64_t launches_
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
             c->ms[p.kind] += ms;
-            c->launches[p.kind] += 1;
+            c->launches[p.kind] += p.first ? 1 : 0;
         }
         c->pool.push_back(p.e0);
         c->pool.push_back(p.e1);
@@ -722,6 +726,7 @@ int slam_grid_create(slam_ctx *c, int G, int xw, int yw, double scale, double of
     }
     g->d.visits = g->visits;
     g->d.pmap_live = nullptr;
+    g->d.redo = nullptr;
     g->d.live_dirty = &g->live_dirty;
     *out = g;
     return slam_grid_reset(c, g);
@@ -736,6 +741,7 @@ int slam_grid_destroy(slam_ctx *c, slam_grid *g)
         if (c->gstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamSynchronize(c->gstream); }
     }
     if (g->pmap_live) (void)hipFree(g->pmap_live);
+    if (g->d.redo) (void)hipFree(g->d.redo);
     if (g->d.pass) (void)hipFree(g->d.pass);   // also holds hit[] and the visit counter
     if (g->pmap_one) (void)hipFree(g->pmap_one);
     if (g->datamap_one) (void)hipFree(g->datamap_one);
@@ -885,6 +891,12 @@ int slam_grid_live_pmap(slam_ctx *c, slam_grid *g, int8_t **pmap_dev_out)
             return fail(SLAM_ERR_NOMEM, "live pmap (%zu bytes): %s", bytes, hipGetErrorString(e));
         }
         g->d.pmap_live = g->pmap_live;
+        if (hipMalloc(reinterpret_cast<void **>(&g->d.redo), ((size_t)g->d.G + 2) * sizeof(int32_t)) != hipSuccess) {
+            g->d.redo = nullptr;                  // (the owner kernels then run without the byte-window fast path)
+            (void)hipGetLastError();
+        } else {
+            HIPCHK(hipMemsetAsync(g->d.redo, 0, ((size_t)g->d.G + 2) * sizeof(int32_t), c->stream));
+        }
         g->live_dirty = true;
         TRY(refresh_live(c, g, c->stream));
     }

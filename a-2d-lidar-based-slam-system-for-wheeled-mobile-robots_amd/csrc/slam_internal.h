@@ -12,22 +12,29 @@
 
 namespace slam {
 
-// Kernel timing: when the ABI layer has armed a pair of events (slam_timing_enable), the next
-// launch carries them as the dispatch's own start / stop events (hipExtLaunchKernelGGL), so
-// they bracket exactly the kernel's execution - what rocprofv3's kernel trace reports - and
-// no marker packets are put into the queue.
-struct LaunchEvents { hipEvent_t e0, e1; };
-extern thread_local LaunchEvents g_launch_ev;
+// Kernel timing: when the ABI layer has opened a timing bracket (slam_timing_enable; `Timed` in
+// slam_abi.hip), every launch inside it asks the bracket for a fresh pair of events and carries
+// them as the dispatch's own start / stop events (hipExtLaunchKernelGGL), so they bracket exactly
+// the kernel's execution - what rocprofv3's kernel trace reports - and no marker packets are put
+// into the queue.  A family that is several launches (the scan matcher's re-do launch, the byte-
+// window ray cast and its fallback) is the sum of its launches.
+struct LaunchTimer {
+    void *self;
+    bool (*next)(void *self, hipEvent_t *e0, hipEvent_t *e1);
+};
+extern thread_local LaunchTimer g_launch_timer;
+inline bool launch_events(hipEvent_t *e0, hipEvent_t *e1)
+{
+    return g_launch_timer.self && g_launch_timer.next(g_launch_timer.self, e0, e1);
+}
 
 #define SLAM_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                          \
     do {                                                                                                              \
-        if (::slam::g_launch_ev.e0) {                                                                                 \
-            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ::slam::g_launch_ev.e0, ::slam::g_launch_ev.e1, \
-                                  0, __VA_ARGS__);                                                                    \
-            ::slam::g_launch_ev.e0 = ::slam::g_launch_ev.e1 = nullptr;                                                \
-        } else {                                                                                                      \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                                      \
+        if (::slam::launch_events(&e0_, &e1_))                                                                        \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0_, e1_, 0, __VA_ARGS__);                      \
+        else                                                                                                          \
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                      \
-        }                                                                                                             \
     } while (0)
 
 
@@ -83,6 +90,7 @@ struct IcpArgs {
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
     int32_t *redo = nullptr;   // [B] scratch: pairs the EXACT launch must re-do (see k_icp); null: no second launch
     int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
+    int polar_copy = 0;        // set by launch_icp: the kernel carves the unpadded second copy of the target (nn_polar)
 };
 
 hipError_t launch_icp(const IcpArgs &a, int dtype, hipStream_t s);
@@ -124,6 +132,9 @@ struct GridDev {
     // the next finalize / read refreshes it with a full pass.
     int8_t *pmap_live;
     bool *live_dirty;
+    // Re-do list of the single-scan owner kernels (allocated with the live pmap): [0] maps listed, [1] workgroups
+    // of the general kernel that have read the list, [2 + k] map numbers.  Empty between launches.
+    int32_t *redo;
     double free_inc, hit_inc;
 };
 
