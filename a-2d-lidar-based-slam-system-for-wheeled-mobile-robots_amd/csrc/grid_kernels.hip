@@ -1397,32 +1397,26 @@ __global__ void __launch_bounds__(kOwnerThreads) k_grid_update_owner_redo(GridDe
 //     length (longest rays in the lowest waves) takes the rank inside a bin from the histogram atomic's return
 //     value and the bin's offset from a wave-level scan that every wave does for itself; the sorted end cells
 //     travel through LDS as packed 16-bit pairs instead of being loaded and computed a second time.
-//   * the sweep keeps BATCH 16-byte read-modify-writes per lane in flight; counters and pmap rule exactly as in
-//     the kernel above (mapping.py:42-50).
+//   * the sweep goes by window rows: a wave takes a row (64 quads of it at a time), so the map addresses are a
+//     scalar row offset plus a per-lane constant, and reads / writes the counters and pmap with non-temporal buffer
+//     loads and stores whose per-lane offset lies beyond the buffer for lanes with nothing to do: BATCH rows per
+//     wave in flight, no branches, no lane masks.  Counters and pmap rule exactly as in the kernel above
+//     (mapping.py:42-50); the pmap arithmetic runs only for quads where something can change.
+//   * what bounds it (tools/ubench_rmw.hip, profiles/r03_ubench_rmw.txt): the chip moves this traffic - 64-byte
+//     pieces read and written back in place, scattered over 14 GB of maps - at 3.8 TB/s with the default cache
+//     policy and 4.75 TB/s non-temporal; a plain streaming copy reaches 4.5 TB/s (reads alone 6.3, writes alone 4.4).
 // ---------------------------------------------------------------------------------
 constexpr int kOwn8Bins = 128;
 constexpr int kOwn8BoxInts = 16;
 constexpr int kOwn8MaxLen = 2048;
-#ifndef SLAM_X8
-#define SLAM_X8 0
-#endif
-#ifndef SLAM_OWN8_THREADS
-#define SLAM_OWN8_THREADS 384
-#endif
-#ifndef SLAM_OWN8_BATCH
-#define SLAM_OWN8_BATCH 8
-#endif
-#ifndef SLAM_OWN8_PIECES
-#define SLAM_OWN8_PIECES 0
-#endif
-#ifndef SLAM_OWN8_LDS
-#define SLAM_OWN8_LDS 53760
-#endif
-constexpr int kOwn8Threads = SLAM_OWN8_THREADS;   // >= kOwn8Bins, a multiple of 64
-constexpr int kOwn8Batch = SLAM_OWN8_BATCH;
-constexpr bool kOwn8Pieces = SLAM_OWN8_PIECES != 0;
+constexpr int kOwn8Threads = 384;       // >= kOwn8Bins, a multiple of 64: six waves, one ray per lane up to 384 beams
+constexpr int kOwn8Batch = 8;           // window rows a wave keeps in flight in the sweep (4 ... 8 measured equal)
 // LDS of a workgroup: 42 allocation granules of 1 280 bytes, so that three workgroups fit a CU's 160 KiB
-constexpr int kOwn8LdsBytes = SLAM_OWN8_LDS;
+constexpr int kOwn8LdsBytes = 53760;
+// cache policy of the sweep's counter and pmap traffic (buffer aux bits: 1 sc0, 2 nt, 16 sc1): every byte is read and
+// written once per launch, and non-temporal loads AND stores run the in-place read-modify-write 24 % faster than the
+// default policy (tools/ubench_rmw.hip: 4.75 against 3.83 TB/s on this access pattern; nt on the stores alone: no gain)
+constexpr int kOwn8Aux = 2;
 constexpr int kOwn8PerCU = 163840 / kOwn8LdsBytes;      // workgroups per CU the register budget is set for
 __host__ __device__ inline size_t own8_fixed_bytes(int threads) { return (size_t)(kOwn8BoxInts + kOwn8Bins) * 4 + (size_t)threads * 4; }
 
@@ -1442,7 +1436,7 @@ __device__ __forceinline__ void lds_or_u32(unsigned addr, unsigned v)
     (void)__hip_atomic_fetch_or((lds_u32_t *)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <class Src, int THREADS, int BATCH, bool PIECES>
+template <class Src, int THREADS, int BATCH>
 __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k_grid_update_owner8(GridDev g, Src src, int win_bytes, int32_t *__restrict__ redo)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1460,15 +1454,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
         if (tid == 0) redo[2 + atomicAdd(&redo[0], 1)] = l;
     };
 
-#if SLAM_X8 & 64
-    return;
-#endif
-#ifdef SLAM_OWN8_STAGGER
-    if (blockIdx.y < 768u) {                                          // experiment: random start phases for the first generation
-        const int slices = (int)((blockIdx.y * 2654435761u) >> 28);  // 0..15
-        for (int k = 0; k < slices * SLAM_OWN8_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles = 3.4 us each
-    }
-#endif
     // this lane's beam: loads first, LDS set-up while they are in flight
     typename Src::Beam beam = src.fetch(l, 0, tid < n ? tid : 0);
     ScanConst c0;
@@ -1481,9 +1466,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     }
     __syncthreads();
     STAMP(0);
-#if SLAM_X8 & 128
-    if (c0.px != 1234.5) return;
-#endif
 
     // pass 1: end cell, length bin, bounding box (mapping.py:30-36)
     int pox = 0, poy = 0, b2 = 0;
@@ -1542,9 +1524,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     }
     __syncthreads();
     STAMP(2);
-#if SLAM_X8 & 256
-    return;
-#endif
 
     // this lane's ray: the tid-th longest
     const bool have = tid < nv;
@@ -1566,9 +1545,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
         const int da_k = rr.steep ? 1 : Hs, da_y = rr.steep ? rr.ystep * Hs : rr.ystep;
         double error = 0.0;                                          // bresenham.py:34
         int rem = have ? rr.dx - 1 : 0;
-#if SLAM_X8 & 16
-        rem = 0; box[5] = 0;
-#endif
         auto advance = [&]() {
             error += rr.derr;                                        // :51
             const bool stepy = error >= 0.5;                         // :53
@@ -1591,9 +1567,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     }
     __syncthreads();
     STAMP(3);
-#if SLAM_X8 & 512
-    return;
-#endif
 
     // From here on a wave works on whole window rows (map x = x0 + r), 64 quads of a row at a time (a quad: 4 cells,
     // one window dword, 16 bytes of counters, 4 of pmap): row and segment are wave-uniform, so the window index and the
@@ -1615,9 +1588,6 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     }
     __syncthreads();
     if (box[6] != box[5]) { give_up(); return; }
-#if SLAM_X8 & 1024
-    return;
-#endif
 
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
     int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
@@ -1647,16 +1617,8 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
                 dd[u] = (incol && r < W) ? win[rc * qrow + c] : 0u;
                 const bool live = dd[u] != 0u || (r == org_r && org_lane);
                 vo[u] = live ? (unsigned)lane << 4 : kSkip;         // byte offset of the lane's quad in the counter row
-#if SLAM_X8 & 4
-                p[u] = u32x4_t{rowoff, rowoff, rowoff, rowoff};
-#else
-                p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff << 2, 0);
-#endif
-#if SLAM_X8 & 1
-                om[u] = 0x32323232u;
-#else
-                om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vo[u] >> 2, rowoff, 0);
-#endif
+                p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff << 2, kOwn8Aux);
+                om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vo[u] >> 2, rowoff, kOwn8Aux);
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
@@ -1675,9 +1637,7 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
                         t7 |= 0x80u << (8u * org_b);
                     }
                 }
-#if !(SLAM_X8 & 2)
-                __builtin_amdgcn_raw_buffer_store_b128(q, rs_pass, vo[u], rowoff << 2, 0);
-#endif
+                __builtin_amdgcn_raw_buffer_store_b128(q, rs_pass, vo[u], rowoff << 2, kOwn8Aux);
                 // pmap (mapping.py:47-50): a touched cell shows 0 or 100 afterwards.  Its byte changes iff it was never
                 // touched before (50: bit 4 is set in 50 only), or it is hit now and was not occupied (bit 6 is set in
                 // 100 only), or its pass count is at or over the threshold now
@@ -1690,17 +1650,13 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
                     occ |= (q.x >= pthr ? 1u : 0u) | (q.y >= pthr ? 0x100u : 0u) | (q.z >= pthr ? 0x10000u : 0u) | (q.w >= pthr ? 0x1000000u : 0u);
                     const uint32_t tm = tb * 255u;
                     const uint32_t out = (o & ~tm) | ((occ * 100u) & tm);
-#if !(SLAM_X8 & 32)
-                    if (out != o) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vo[u] >> 2, rowoff, 0);
-#endif
+                    if (out != o) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vo[u] >> 2, rowoff, kOwn8Aux);
                 }
             }
         }
     }
     // the hits last (mapping.py:45): fire-and-forget atomics, which the sweep's loads would otherwise queue behind
-#if !(SLAM_X8 & 8)
     if (have) atomicAdd(&hit[(size_t)ex * g.yw + ey], 1u);
-#endif
 #ifdef SLAM_STAMPS
     __syncthreads();
 #endif
@@ -1760,7 +1716,7 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
         // whatever it leaves on the re-do list is cast by the general kernel behind it
         if (g.redo && n <= kOwn8Threads && n <= kOwnerThreads && g.xw <= 65535 && g.yw <= 65535 && (long)g.xw * g.yw < (1L << 29)) {
             const int own8_lds = kOwn8LdsBytes + kLdsGuard, own8_win = (int)(kOwn8LdsBytes - own8_fixed_bytes(kOwn8Threads));
-            SLAM_LAUNCH((k_grid_update_owner8<Src, kOwn8Threads, kOwn8Batch, kOwn8Pieces>), dim3(1, L), dim3(kOwn8Threads), own8_lds, s,
+            SLAM_LAUNCH((k_grid_update_owner8<Src, kOwn8Threads, kOwn8Batch>), dim3(1, L), dim3(kOwn8Threads), own8_lds, s,
                         g, src, own8_win, g.redo);
             SLAM_LAUNCH((k_grid_update_owner_redo<Src, 1>), dim3(std::min(L, 512)), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells, g.redo);
             return hipGetLastError();

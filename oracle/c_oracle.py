@@ -46,6 +46,8 @@ def lib():
         L.orc_compose_pose.argtypes = [_dp, _dp]
         L.orc_world_points.argtypes = [_dp, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_bresenham.argtypes = [C.c_int] * 4 + [_ip, C.c_int]
+        L.orc_walk_end_mismatches.argtypes = [C.c_int]
+        L.orc_walk_end_mismatches.restype = C.c_long
         L.orc_bresenham.restype = C.c_int
         L.orc_grid_create.argtypes = [C.c_int, C.c_int] + [C.c_double] * 6
         L.orc_grid_create.restype = C.c_void_p
@@ -136,6 +138,11 @@ def bresenham(start, end):
     xy = np.empty(2 * cap, dtype=np.int32)
     n = lib().orc_bresenham(int(start[0]), int(start[1]), int(end[0]), int(end[1]), xy, cap)
     return xy[: 2 * n].reshape(-1, 2)
+
+
+def walk_end_mismatches(max_dx):
+    """(dx, dy) pairs up to max_dx whose float-error walk does not end in the cell of its other end."""
+    return int(lib().orc_walk_end_mismatches(int(max_dx)))
 
 
 class Grid:

@@ -251,6 +251,26 @@ int orc_bresenham(int x0, int y0, int x1, int y1, int32_t *xy, int cap)
     return len;
 }
 
+/* Property of the walk above that the byte-window ray cast relies on (k_grid_update_owner8): the float-error walk
+ * of bresenham.py:45-55 ends in the cell of its other end, i.e. after dx error updates exactly dy of them stepped y.
+ * Counts the (dx, dy) pairs with 1 <= dx <= max_dx, 0 <= dy <= dx for which it does not (expected: none). */
+long orc_walk_end_mismatches(int max_dx)
+{
+    long bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : bad)
+    for (int dx = 1; dx <= max_dx; ++dx)
+        for (int dy = 0; dy <= dx; ++dy) {
+            double error = 0.0, derr = (double)dy / (double)dx;       /* :34-35 */
+            int y = 0;
+            for (int k = 0; k < dx; ++k) {
+                error += derr;                                    /* :51 */
+                if (error >= 0.5) { ++y; error -= 1.0; }          /* :53-55 */
+            }
+            bad += y != dy;
+        }
+    return bad;
+}
+
 /* a-9/a-10: W12m/mapping.py:8-51 with the index rule generalised to
  * int(scale*(x+offset)) (the reference hard-codes 10 and 10, :33-36).  State: datamap
  * (float64, the reference's own accumulator), pmap, and integer pass / hit counters

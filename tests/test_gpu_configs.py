@@ -363,6 +363,65 @@ def test_single_scan_owner_kernel_fans(slam, case):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["count_127", "count_128_overflows", "tall_box_two_segments", "box_at_capacity", "box_over_capacity",
+                                  "leaves_map", "origin_in_corner", "unaligned_rows", "one_ray", "neighbour_cells_only", "hits_pile_up"])
+def test_single_scan_byte_window_kernel_cases(slam, case):
+    """The byte-window owner kernel (k_grid_update_owner8: one scan of at most 384 beams into a map with a live pmap)
+    and its hand-over to the general kernel: 127 identical rays (the largest count a window byte holds) and 128 (the
+    byte-sum check fails: re-do list); a box taller than 256 cells (two 64-quad segments per window row); boxes just
+    inside and just beyond the window's capacity; rays that leave the map; an origin in the map's corner cell; rows
+    that do not start on a quad; a single ray; rays to the origin's neighbours only (no cell between origin and
+    hit); many rays ending in one cell.  Three passes each: later passes meet non-zero counters and a settled pmap."""
+    xw, yw, scale, off_x, off_y = 400, 400, 20.0, 10.0, 10.0
+    org = (200, 201)
+    if case == "count_127":
+        cells = [(260, 230)] * 127 + _ring(150, 250, 150, 250, 5)
+    elif case == "count_128_overflows":
+        cells = [(260, 230)] * 128 + _ring(150, 250, 150, 250, 5)
+    elif case == "tall_box_two_segments":
+        org = (180, 200)
+        cells = _ring(150, 230, 30, 370, 3)                        # 81 x 341 cells: rows of 86 quads
+    elif case == "box_at_capacity":
+        org = (200, 200)
+        cells = _ring(88, 322, 95, 310, 4)                         # 235 x 216 = 50 760 window bytes <= 51 584
+    elif case == "box_over_capacity":
+        org = (200, 200)
+        cells = _ring(80, 330, 90, 310, 4)                         # 251 x 224: beyond the window -> general kernel
+    elif case == "leaves_map":
+        cells = _ring(150, 250, 150, 250, 5) + [(450, 200), (200, -30), (-5, -5)]
+    elif case == "origin_in_corner":
+        org = (0, 0)
+        cells = [(x, 120) for x in range(0, 150, 3)] + [(140, y) for y in range(0, 120, 3)]
+    elif case == "unaligned_rows":
+        org = (199, 203)
+        cells = _ring(151, 249, 153, 251, 3)                       # y range 153 .. 251: rows start one cell past a quad
+    elif case == "one_ray":
+        cells = [(230, 190)]
+    elif case == "neighbour_cells_only":
+        cells = [(199, 200), (201, 202), (200, 202), (201, 201), (200, 201)]   # the last one: start == end, empty path
+    else:
+        cells = [(240, 240)] * 60 + [(240, 241)] * 50 + [(160, 170)] * 3
+    ox = np.array([(c[0] + 0.5) / scale - off_x for c in cells])
+    oy = np.array([(c[1] + 0.5) / scale - off_y for c in cells])
+    cx, cy = (org[0] + 0.5) / scale - off_x, (org[1] + 0.5) / scale - off_y
+    assert len(cells) <= 384
+    ctx = slam.Context(0)
+    g = slam.DeviceGrid(1, xw, yw, scale, off_x, off_y, context=ctx)
+    g.live_pmap()
+    og = co.Grid(xw, yw, scale, off_x, off_y)
+    for k in range(3):
+        g.update_host(ox, oy, cx, cy)
+        og.update(ox, oy, cx, cy)
+        ctx.check_status()
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt), (case, k, int(np.sum(r["pass"] != og.pass_cnt)))
+        assert np.array_equal(r["hit"], og.hit_cnt), (case, k)
+        assert np.array_equal(r["pmap"], og.pmap), (case, k, int(np.sum(r["pmap"] != og.pmap)))
+        assert g.visits() == og.visits, (case, k)
+    g.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", ["random_ranges", "inf_and_tiny", "span_270deg", "span_over_one_turn", "quantised_ties",
                                   "near_origin", "n2", "n9", "n63", "nan_ranges", "f16_random", "f32_room"])
 def test_scan_window_nearest_neighbour_edge_scans(slam, syn, case):
