@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "slam_internal.h"
+#include "slam_stamps.h"
 
 namespace slam {
 
@@ -238,52 +239,12 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
 // workgroup for the whole launch and none of its lines has been loaded before (no stale L1 copy
 // can exist), so nothing has to be written back or invalidated: a device-wide __threadfence()
 // here made every owner write the XCD's whole L2 back.
-#ifndef SLAM_OWNER_FENCE
-#define SLAM_OWNER_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-// Diagnostic build (-DSLAM_STAMPS, never shipped): thread 0 of every window workgroup adds the
-// shader-clock cycles of each phase to 64-bit counters behind the context's status word
-// (status + 8 ints), read back by slam_debug_read.
-#ifdef SLAM_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0
-#define STAMP(k)                                                                                         \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
-            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_t0);           \
-            st_t0 = t_;                                                                                  \
-        }                                                                                                \
-    } while (0)
-#define STAMP_END(k)                                                                                     \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
-            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_first);        \
-            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k) + 1, 1ull);             \
-        }                                                                                                \
-    } while (0)
-#else
-#define STAMP_DECL
-#define STAMP(k)
-#define STAMP_END(k)
-#endif
-#ifndef SLAM_EXP
-#define SLAM_EXP 0      // diagnostic builds: 1 no pmap loads, 2 no pass stores, 3 no loads, 4 no loads and no pass stores (wrong maps!)
-#endif
-#ifndef SLAM_SWEEP_BATCH
-#define SLAM_SWEEP_BATCH 4
-#endif
-#ifndef SLAM_WIN_CELLS
-#define SLAM_WIN_CELLS 36864
-#endif
-constexpr int kWinCells = SLAM_WIN_CELLS;     // 16-bit cells: 72 KiB of LDS
+__device__ __forceinline__ void owner_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int kWinCells = 36864;     // 16-bit cells: 72 KiB of LDS
 constexpr int kWinMaxGroup = 64;     // scans per workgroup
 constexpr int kSortBins = 128;        // ray-length histogram (4 cells per bin)
 constexpr int kMaxSortRays = 8192;    // rays per workgroup that can be length-sorted (u16 ids in LDS)
-#ifndef SLAM_RAYS_PER_LANE
-#define SLAM_RAYS_PER_LANE 4
-#endif
-constexpr int kRaysPerLane = SLAM_RAYS_PER_LANE;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
+constexpr int kRaysPerLane = 4;     // lanes per workgroup = rays / kRaysPerLane (rays are dealt to waves dynamically)
 
 // mapping.py:47-50 applied to the integer counters (see the header comment).
 struct OccRule {
@@ -453,7 +414,6 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
         int lx = ry.steep ? ry.y0 : ry.x0, ly = ry.steep ? ry.x0 : ry.y0;
         int hx = -1, hy = -1;
         double error = 0.0;                                           // bresenham.py:34
-#ifndef SLAM_NO_FAST_WALK
         // A ray whose two end cells lie in the window stays in it (a Bresenham path never leaves the box
         // of its ends): no bounds checks, the cell kept as ONE running halfword index, four steps per
         // wave-wide loop test.  The path's last cell is the endpoint's cell (mapping.py:44-45); it takes the
@@ -495,7 +455,6 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
             }
             continue;
         }
-#endif
         for (int k = 0; k <= ry.dx; ++k) {                            // :45
             bool last = k == klast;
             unsigned wx = (unsigned)(lx - wx0), wy = (unsigned)(ly - wy0);
@@ -687,7 +646,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         int W = 0, H = 0, covers = 1;
         int fastwin = 0, strip_w = 0;                                // strips of the single-scan owner form
         if (x0 <= x1 && y0 <= y1) {
-#ifndef SLAM_NO_FAST_SWEEP
             // Fast owner sweep (see the end of the kernel): one scan, one hit occupies, and the window,
             // widened to whole 64-byte pieces of the counter rows (16 cells), still holds every cell.
             if (fused && cnt == 1 && nrays < 32768 && g.hit_levels == 1 && (g.yw & 15) == 0) {
@@ -696,7 +654,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 while ((long)Ws * Ha > win_cells && S < Wb) { ++S; Ws = (Wb + S - 1) / S; }
                 if ((long)Ws * Ha <= win_cells) { y0 = ya; y1 = ya + Ha - 1; fastwin = S; strip_w = Ws; }
             }
-#endif
             if (fused) y0 &= ~3;                                      // quads of the fused flush line up with the window's dwords
             else if (pair64) y0 &= ~1;                                // the window's dwords line up with 8-byte pairs of counters
             W = x1 - x0 + 1; H = y1 - y0 + 1;
@@ -719,7 +676,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
         }
         box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers; box[10] = fastwin; box[11] = strip_w;
-#ifndef SLAM_NO_HALVES
         if (halves_ok && !covers && !fastwin && W > 0) {
             // the whole box does not fit: one window per direction half.  A half that is still too large keeps
             // the sub-rectangle next to the origin column (its rays start there) and leaves the rest to the
@@ -745,7 +701,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             }
             if (any) box[34] = 2;
         }
-#endif
     }
     __syncthreads();
     STAMP(1);                                   // pass 1: endpoints, bounding box, histogram
@@ -844,7 +799,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         int8_t *pm = g.pmap_live + (size_t)gi * g.xw * g.yw;
         const int qrow = H >> 2;                                      // H is a multiple of 16 here
         const unsigned qinv = (unsigned)((0x100000000ull + (unsigned)qrow - 1) / (unsigned)qrow);   // q / qrow == umulhi(q, qinv), q < 2^16
-        constexpr int kBatch = SLAM_SWEEP_BATCH;
+        constexpr int kBatch = 4;                                     // 16-byte read-modify-writes a lane keeps in flight
         for (int strip = 0; strip < strips; ++strip) {
         const int sx0 = wx0 + strip * strip_w, SW = min(strip_w, wx0 + W - sx0), total = SW * qrow;
         if (strip) __syncthreads();                                   // the previous strip's sweep has read the window
@@ -874,16 +829,8 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 const unsigned long long m = __ballot((d0[u] | d1[u]) != 0u);
                 live[u] = ((m >> (lane & 60)) & 0xFull) != 0ull;
                 if (live[u]) {
-#if SLAM_EXP == 3 || SLAM_EXP == 4
-                    p[u] = make_uint4(0, 0, 0, 0);
-#else
                     p[u] = *reinterpret_cast<const uint4 *>(pass + at[u]);
-#endif
-#if SLAM_EXP == 1 || SLAM_EXP == 3 || SLAM_EXP == 4
-                    om[u] = 0;
-#else
                     om[u] = *reinterpret_cast<const uint32_t *>(pm + at[u]);
-#endif
                 }
             }
 #pragma unroll
@@ -891,9 +838,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 if (!live[u]) continue;
                 const uint32_t c0 = d0[u] & 0x7fffu, c1 = (d0[u] >> 16) & 0x7fffu, c2 = d1[u] & 0x7fffu, c3 = (d1[u] >> 16) & 0x7fffu;
                 p[u].x += c0; p[u].y += c1; p[u].z += c2; p[u].w += c3;
-#if SLAM_EXP != 2 && SLAM_EXP != 4
                 *reinterpret_cast<uint4 *>(pass + at[u]) = p[u];
-#endif
                 if (!(d0[u] | d1[u])) continue;
                 const uint32_t o = om[u];
                 // per byte: 1 where the cell is occupied afterwards - it was (bit 6 is set in 100 only, not
@@ -908,16 +853,12 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 if (out != o) *reinterpret_cast<uint32_t *>(pm + at[u]) = out;
             }
         }
-#ifdef SLAM_STAMPS
-        __syncthreads();
-#endif
+        STAMP_SYNC();
         STAMP(4);                                   // sweep
         }   // strips
-#ifdef SLAM_STAMPS
-        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + 7, (unsigned long long)strips);
-#endif
+        STAMP_COUNT(7, strips);
     } else if (exclusive && g.pmap_live) {
-        SLAM_OWNER_FENCE();
+        owner_fence();
         __syncthreads();
         const int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         if (x0 <= x1 && y0 <= y1) {
@@ -930,7 +871,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 const int total = rows * qrow;
                 // (pm is a char pointer and may alias anything for the compiler: the loads of a batch
                 // are issued before its stores by hand)
-                constexpr int kBatch = 4;
+                constexpr int kBatch = 4;                                     // 16-byte read-modify-writes a lane keeps in flight
                 for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
                     uint4 p[kBatch], h[kBatch];
                     size_t at[kBatch];
@@ -1013,10 +954,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
 // Rays that leave the map (mapping.py:41 drops their outside cells) are rare and take a plain
 // bounds-checked walk per strip.
 // ---------------------------------------------------------------------------------
-#ifndef SLAM_OWNER_THREADS
-#define SLAM_OWNER_THREADS 512
-#endif
-constexpr int kOwnerThreads = SLAM_OWNER_THREADS;   // 8 waves: two workgroups per CU at up to 128 VGPRs
+constexpr int kOwnerThreads = 512;   // 8 waves: two workgroups per CU at up to 128 VGPRs
 constexpr int kOwnerMaxRays = 2;                    // rays per lane (template parameter: 1 up to 512 beams)
 
 struct OwnRay {
@@ -1283,7 +1221,7 @@ __device__ __forceinline__ void owner_cast(const GridDev &g, const Src &src, int
         __syncthreads();
         STAMP(3);
         // sweep: 4 lanes per 64-byte piece of a counter row
-        constexpr int kBatch = SLAM_SWEEP_BATCH;
+        constexpr int kBatch = 4;                                     // 16-byte read-modify-writes a lane keeps in flight
         for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
             uint4 p[kBatch];
             uint32_t om[kBatch], d0[kBatch], d1[kBatch];
@@ -1332,9 +1270,7 @@ __device__ __forceinline__ void owner_cast(const GridDev &g, const Src &src, int
                 }
             }
         }
-#ifdef SLAM_STAMPS
-        __syncthreads();
-#endif
+        STAMP_SYNC();
         STAMP(4);
     }
     unsigned tot = wave_sum_u32(nvis);
@@ -1347,9 +1283,7 @@ __device__ __forceinline__ void owner_cast(const GridDev &g, const Src &src, int
     }
     __syncthreads();
     if (tid == 0 && *wg_visits) atomicAdd(visit_slot(g.visits), *wg_visits);
-#ifdef SLAM_STAMPS
-    if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + 7, (unsigned long long)strips);
-#endif
+    STAMP_COUNT(7, strips);
     STAMP_END(5);
     lds_guard_check(guard, g.status);
 }
@@ -1657,9 +1591,7 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     }
     // the hits last (mapping.py:45): fire-and-forget atomics, which the sweep's loads would otherwise queue behind
     if (have) atomicAdd(&hit[(size_t)ex * g.yw + ey], 1u);
-#ifdef SLAM_STAMPS
-    __syncthreads();
-#endif
+    STAMP_SYNC();
     STAMP(4);
     STAMP_END(5);
     lds_guard_check(guard, g.status);
@@ -1681,10 +1613,7 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     int groups = (scans + group - 1) / group;
     long rays = (long)group * n;
     long want = (rays + kRaysPerLane - 1) / kRaysPerLane;
-#ifndef SLAM_WIN_MAX_THREADS
-#define SLAM_WIN_MAX_THREADS 1024
-#endif
-    int threads = want >= SLAM_WIN_MAX_THREADS ? SLAM_WIN_MAX_THREADS : (int)(((want + kWave - 1) / kWave) * kWave);
+    int threads = want >= kMaxWaves * kWave ? kMaxWaves * kWave : (int)(((want + kWave - 1) / kWave) * kWave);
     if (threads < 128) threads = 128;
     // one workgroup per map and no other writer: single stream (L == 1) or one map per stream
     const int exclusive = g.pmap_live && groups == 1 && !got && (L == 1 || src.maps_are_private());
@@ -1693,10 +1622,8 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     // exclusive sweep (a streaming pass over the touched rectangle) need lanes for memory
     // operations in flight even when there are few rays (measured on 10 000 single-scan groups:
     // 2.88 ms with 128 threads, 2.05 ms with 512)
-#ifndef SLAM_WIN_MIN_THREADS
-#define SLAM_WIN_MIN_THREADS 512
-#endif
-    if (threads < SLAM_WIN_MIN_THREADS) threads = SLAM_WIN_MIN_THREADS;
+    constexpr int kWinMinThreads = 512;
+    if (threads < kWinMinThreads) threads = kWinMinThreads;
     const int sort_cap = win_sort_cap((long)group * n);
     const int win_cells = win_cells_for(group, sort_cap);
     // one scan per map, cast by the map's only writer, live pmap, the reference's one-hit-occupies rule
@@ -1798,10 +1725,7 @@ hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const
 // ---------------------------------------------------------------------------------
 constexpr int kTileSteps = 2048;                 // rays with dx < kTileSteps are recorded
 constexpr int kTileWords = kTileSteps / 32;
-#ifndef SLAM_TILE_SIDE
-#define SLAM_TILE_SIDE 192
-#endif
-constexpr int kTileSide = SLAM_TILE_SIDE;        // 192 x 192 16-bit cells = the 72 KiB window
+constexpr int kTileSide = 192;        // 192 x 192 16-bit cells = the 72 KiB window
 
 struct RayRec {
     int x0, y0, dx, yend;                        // walk coordinates; yend = y of the cell at step dx
@@ -1984,7 +1908,6 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
         uint32_t word = bw[w];
         int y = rec.y0 + ystep * ((int)ts.prefix[rid * kTileWords + w] + __popc(word & ((1u << (k0 & 31)) - 1u)));
         word >>= (k0 & 31);
-#ifndef SLAM_TILE_OLD_WALK
         // The cell of walk step k as the LDS byte address of its 16-bit counter, advanced incrementally (while
         // the ray is outside the tile's rows the address is virtual: it is only used inside them).  The path's
         // last cell takes the hit and no pass count (mapping.py:44-45): it is the ray's first or last step and is
@@ -2047,33 +1970,6 @@ __global__ void __launch_bounds__(1024) k_tile_cast(GridDev g, TileScratch ts, i
                 ++w;
             }
         }
-#else
-        // cell of walk step k in window coordinates, advanced incrementally
-        int wa = rec.x0 + k0 - a0;                                   // along the walk axis: 0 .. a1 - a0
-        bool gone = false;
-        for (int k = k0; k <= k1 && !gone;) {
-            const int kend = min(k1, (w << 5) + 31);
-            const uint32_t next = kend < k1 ? bw[w + 1] : 0u;        // in flight while this word is walked
-            const int nb = kend - k + 1;
-            const int yafter = y + ystep * __popc(nb == 32 ? word : (word & ((1u << nb) - 1u)));
-            if (ystep > 0 ? yafter < b0 : yafter > b1) {             // the whole word stays short of the tile's rows
-                y = yafter; k = kend + 1; wa += nb; word = next; ++w;
-                continue;
-            }
-            for (; k <= kend; ++k, ++wa) {
-                if (ystep > 0 ? y > b1 : y < b0) { gone = true; break; }   // left the tile for good (y is monotone)
-                if (y >= b0 && y <= b1 && k != klast) {
-                    unsigned wb = (unsigned)(y - b0);
-                    unsigned wx = steep ? wb : (unsigned)wa, wy = steep ? (unsigned)wa : wb;
-                    atomicAdd(&win[wx * Hs + (wy >> 1)], 1u << ((wy & 1u) * 16u));
-                }
-                y += (word & 1u) ? ystep : 0;
-                word >>= 1;
-            }
-            word = next;
-            ++w;
-        }
-#endif
     }
     __syncthreads();
     const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)W);

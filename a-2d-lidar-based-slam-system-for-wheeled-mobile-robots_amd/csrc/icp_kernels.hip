@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "slam_internal.h"
+#include "slam_stamps.h"
 
 namespace slam {
 
@@ -230,10 +231,7 @@ __device__ __forceinline__ Rigid2 kabsch_from_sums_wave(double cax, double cay, 
 // farther than U >= the final minimum, marked blocks are scanned in index order with strict
 // '<', and the result (index and distance) is bit-identical to the exhaustive scan, ties
 // included.
-#ifndef SLAM_NN_BLOCK
-#define SLAM_NN_BLOCK 16
-#endif
-constexpr int kNNBlock = SLAM_NN_BLOCK;
+constexpr int kNNBlock = 16;
 constexpr int kNNStride = kNNBlock + 1;   // LDS slots per block: the pad spreads the blocks over the banks
 static_assert(kNNBlock == 16, "tslot() assumes 16-point blocks");
 
@@ -273,10 +271,8 @@ struct Best {
     __device__ __forceinline__ void take(double d, int k)
     {
         const bool c = d < d2;
-#ifndef SLAM_NO_TIE_TRACK
         const double dk = d * kTieAbove;                             // (off the compare chain: it depends on the candidate alone)
         ambm |= __ballot(c) & ~__ballot(dk < d2);
-#endif
         d2 = fmin(d2, d);                                            // NaN never lowers it
         j = c ? k : j;
     }
@@ -358,9 +354,7 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
                     double2 tk = t[k];
                     const double d = dist2(sx, sy, tk.x, tk.y);
                     const bool c = d < b.d2;
-#ifndef SLAM_NO_TIE_TRACK
                     b.ambm |= __ballot(c) & ~__ballot(d * kTieAbove < b.d2);
-#endif
                     b.d2 = fmin(b.d2, d);                            // NaN never lowers it
                     kk = c ? k : kk;                                 // (the index within the block: constants)
                 }
@@ -392,18 +386,12 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // Queries whose window is wide (no good match: newly visible surfaces) or whose bound does not
 // apply (closer to the origin than 2 sqrt(U), NaN) are left to the box search (`big`).
 // ---------------------------------------------------------------------------------
-#ifndef SLAM_POLAR_MAX
-#define SLAM_POLAR_MAX 32
-#endif
-constexpr int kPolarMax = SLAM_POLAR_MAX;     // widest window (beams) the polar search takes ...
+constexpr int kPolarMax = 32;     // widest window (beams) the polar search takes ...
 // ... in the launch shape that re-guesses useless first guesses (PROBE); the shapes without take windows four times
 // as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
 // lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
 constexpr int kPolarMaxLone = 96;
-#ifndef SLAM_POLAR_PROBE
-#define SLAM_POLAR_PROBE 8
-#endif
-constexpr int kPolarProbe = SLAM_POLAR_PROBE;                // beams either side of a useless guess that are tried for a better one
+constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
 constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
 template <typename T> struct StoreSlack { static constexpr float ang = 2e-7f; };              // float64 points
@@ -486,7 +474,6 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         }
     };
     bool fits = window(seed, lo, hi);
-#ifndef SLAM_NO_PROBE
     // (PROBE: in the launch shape for a full chip - three queries per lane - where it saves instructions:
     // 10 000 pairs 0.425 -> 0.395 ms.  A lone 999-pair launch with two queries per lane is bound by the latency
     // of its longest solves and got SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter:
@@ -508,7 +495,6 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         hi = fits1 ? hi1 : hi;
         fits = fits || fits1;
     }
-#endif
     big = active && !fits;
     const bool go = active && !big;
     // three index ranges in ascending order: wrapped from above | the window | wrapped from below
@@ -653,71 +639,8 @@ constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collap
 __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
 constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the reductions, two alternating buffers
 
-// Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles
-// of each phase to the 64-bit counters behind the status word (slam_debug_read): [0] staging, [1]
-// search, [2] centroid reduction, [3] products + reduction, [4] Kabsch + transform, [5] final T;
-// [6..9]: phases 1..4 of the FIRST iteration (the others hold iterations >= 1), [10] iterations, [11] pairs, [12] lifetimes,
-// [13] lifetimes on the 100 MHz clock, [14] 2^62 - earliest start, [15] latest end (100 MHz clock).
-#ifdef SLAM_STAMPS_ICP
-#define ISTAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0, st_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_big[4] = {0, 0, 0, 0}, st_real = __builtin_amdgcn_s_memrealtime()
-#define ISTAMP(k)                                                                                        \
-    do {                                                                                                 \
-        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
-        st_acc[k] += t_ - st_t0;                                                                         \
-        st_t0 = t_;                                                                                      \
-    } while (0)
-#if SLAM_STAMPS_ICP == 2   /* when do pairs start and end?  [0..11], [12..23]: histograms in 15 us buckets from the first start; [24]: that start */
-#define ISTAMP_END(iters)                                                                                \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
-            unsigned long long base_ = atomicCAS(c_ + 24, 0ull, st_real);                                \
-            if (base_ == 0ull) base_ = st_real;                                                          \
-            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
-            long long s0_ = (long long)(st_real - base_) / 1500, s1_ = (long long)(r_ - base_) / 1500;   \
-            atomicAdd(c_ + min(max(s0_, 0ll), 11ll), 1ull);                                              \
-            atomicAdd(c_ + 12 + min(max(s1_, 0ll), 11ll), 1ull);                                         \
-        }                                                                                                \
-    } while (0)
-#define ISTAMP_BIG(it, big)
-#else
-#define ISTAMP_BIG(it, big)                                                                              \
-    do {                                                                                                 \
-        st_big[(it) == 0 ? 0 : 2] += __popcll(__ballot(big));                                            \
-        st_big[(it) == 0 ? 1 : 3] += __any(big) ? 1 : 0;                                                 \
-    } while (0)
-#define ISTAMP_END(iters)                                                                                \
-    do {                                                                                                 \
-        if ((threadIdx.x & 63) == 0)                                                                     \
-            for (int k_ = 0; k_ < 4; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(a.status + 8) + 21 + k_, st_big[k_]); \
-        if (threadIdx.x == 0) {                                                                          \
-            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
-            for (int k_ = 0; k_ < 10; ++k_) atomicAdd(c_ + k_, st_acc[k_]);                              \
-            for (int k_ = 0; k_ < 5; ++k_) atomicAdd(c_ + 16 + k_, st_acc[10 + k_]);                      \
-            atomicAdd(c_ + 10, (unsigned long long)(iters));                                             \
-            atomicAdd(c_ + 11, 1ull);                                                                    \
-            atomicAdd(c_ + 12, __builtin_amdgcn_s_memtime() - st_first);                                 \
-            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
-            atomicAdd(c_ + 13, r_ - st_real);                                                            \
-            atomicMax(c_ + 14, (1ull << 62) - st_real);                                                  \
-            atomicMax(c_ + 15, r_);                                                                      \
-        }                                                                                                \
-    } while (0)
-#endif
-#else
-#define ISTAMP_DECL
-#define ISTAMP(k)
-#define ISTAMP_BIG(it, big)
-#define ISTAMP_END(iters)
-#endif
-
-#ifdef SLAM_ICP_SGPR
-#define SLAM_ICP_ATTR __attribute__((amdgpu_num_sgpr(SLAM_ICP_SGPR)))
-#else
-#define SLAM_ICP_ATTR
-#endif
 template <typename T, int QPT, int UNROLL, bool PROBE, bool EXACT>
-__global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
+__global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 {
     // EXACT: the second launch of every batch.  It re-does, with the reference's own nearest-neighbour loop
     // (nn_exact), the pairs in which the first launch saw a best undercut its predecessor by less than a class
@@ -760,9 +683,7 @@ __global__ void __launch_bounds__(1024) SLAM_ICP_ATTR k_icp(IcpArgs a)
     ISTAMP(10);
     stage_boxes(n_tar, tarL, boxes, boxes4);
     ISTAMP(11);
-#ifndef SLAM_NO_POLAR
     if (a.ranges && has_p) polar_probe(tar, n_tar, geo);
-#endif
     ISTAMP(12);
 
     double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
@@ -967,9 +888,6 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     // (up to 4 544 beams; larger scans, up to the documented 8 192, and point clouds go by the box search alone)
     a.polar_copy = (a.ranges && lds_base + icp_polar_bytes(a.n_tar) <= 160 * 1024) ? 1 : 0;
     size_t lds = lds_base + (a.polar_copy ? icp_polar_bytes(a.n_tar) : 0);
-#ifdef SLAM_ICP_LDS_PAD
-    if (a.B > 64) lds += SLAM_ICP_LDS_PAD;      // tuning experiments: fewer resident workgroups per CU
-#endif
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q, U, P)                                                                                  \
@@ -996,13 +914,7 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     // per trip are as fast as two when the chip is full and faster when it is not - four overlapping 999-pair
     // replays 8.5 -> 8.9 M scans/s - since the candidates come from the unpadded copy.)
     if (qpt <= 1) SLAM_ICP_CASE(1, 4, false)
-#ifndef SLAM_Q2_U
-#define SLAM_Q2_U 4
-#endif
-#ifndef SLAM_Q2_P
-#define SLAM_Q2_P false
-#endif
-    else if (qpt <= 2) SLAM_ICP_CASE(2, SLAM_Q2_U, SLAM_Q2_P)
+    else if (qpt <= 2) SLAM_ICP_CASE(2, 4, false)
     else if (qpt <= 3) SLAM_ICP_CASE(3, 4, true)
     else if (qpt <= 4) SLAM_ICP_CASE(4, 2, true)
     else if (qpt <= 8) SLAM_ICP_CASE(8, 2, true)

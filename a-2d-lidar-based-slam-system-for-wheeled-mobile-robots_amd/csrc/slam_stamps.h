@@ -1,0 +1,98 @@
+// Diagnostic builds only (never shipped): in-kernel phase timers of the ray-cast and scan-matching kernels.
+//   -DSLAM_STAMPS      grid kernels: thread 0 of every workgroup adds the shader-clock cycles of each phase to 64-bit
+//                      counters behind the context's status word (status + 8 ints)
+//   -DSLAM_STAMPS_ICP  k_icp: the same per scan pair (not together with SLAM_STAMPS: same counters)
+// slam_debug_read (slam_abi.hip, compiled in only with one of the two) returns and clears the counters.  Without the
+// switches every macro below is empty.
+#pragma once
+
+// ---- grid kernels: STAMP_DECL at kernel entry, STAMP(k) closes phase k, STAMP_END(k): [k] lifetime, [k + 1] workgroups
+#ifdef SLAM_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_t0);           \
+            st_t0 = t_;                                                                                  \
+        }                                                                                                \
+    } while (0)
+#define STAMP_END(k)                                                                                     \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_first);        \
+            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k) + 1, 1ull);             \
+        }                                                                                                \
+    } while (0)
+#define STAMP_SYNC() __syncthreads()        /* so that a phase's time is the workgroup's, not thread 0's */
+#define STAMP_COUNT(k, v)                                                                                \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), (unsigned long long)(v)); \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_END(k)
+#define STAMP_SYNC()
+#define STAMP_COUNT(k, v)
+#endif
+
+// Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles
+// of each phase to the 64-bit counters behind the status word (slam_debug_read): [0] staging, [1]
+// search, [2] centroid reduction, [3] products + reduction, [4] Kabsch + transform, [5] final T;
+// [6..9]: phases 1..4 of the FIRST iteration (the others hold iterations >= 1), [10] iterations, [11] pairs, [12] lifetimes,
+// [13] lifetimes on the 100 MHz clock, [14] 2^62 - earliest start, [15] latest end (100 MHz clock).
+#ifdef SLAM_STAMPS_ICP
+#define ISTAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0, st_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_big[4] = {0, 0, 0, 0}, st_real = __builtin_amdgcn_s_memrealtime()
+#define ISTAMP(k)                                                                                        \
+    do {                                                                                                 \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+        st_acc[k] += t_ - st_t0;                                                                         \
+        st_t0 = t_;                                                                                      \
+    } while (0)
+#if SLAM_STAMPS_ICP == 2   /* when do pairs start and end?  [0..11], [12..23]: histograms in 15 us buckets from the first start; [24]: that start */
+#define ISTAMP_END(iters)                                                                                \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
+            unsigned long long base_ = atomicCAS(c_ + 24, 0ull, st_real);                                \
+            if (base_ == 0ull) base_ = st_real;                                                          \
+            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
+            long long s0_ = (long long)(st_real - base_) / 1500, s1_ = (long long)(r_ - base_) / 1500;   \
+            atomicAdd(c_ + min(max(s0_, 0ll), 11ll), 1ull);                                              \
+            atomicAdd(c_ + 12 + min(max(s1_, 0ll), 11ll), 1ull);                                         \
+        }                                                                                                \
+    } while (0)
+#define ISTAMP_BIG(it, big)
+#else
+#define ISTAMP_BIG(it, big)                                                                              \
+    do {                                                                                                 \
+        st_big[(it) == 0 ? 0 : 2] += __popcll(__ballot(big));                                            \
+        st_big[(it) == 0 ? 1 : 3] += __any(big) ? 1 : 0;                                                 \
+    } while (0)
+#define ISTAMP_END(iters)                                                                                \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0)                                                                     \
+            for (int k_ = 0; k_ < 4; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(a.status + 8) + 21 + k_, st_big[k_]); \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long *c_ = reinterpret_cast<unsigned long long *>(a.status + 8);              \
+            for (int k_ = 0; k_ < 10; ++k_) atomicAdd(c_ + k_, st_acc[k_]);                              \
+            for (int k_ = 0; k_ < 5; ++k_) atomicAdd(c_ + 16 + k_, st_acc[10 + k_]);                      \
+            atomicAdd(c_ + 10, (unsigned long long)(iters));                                             \
+            atomicAdd(c_ + 11, 1ull);                                                                    \
+            atomicAdd(c_ + 12, __builtin_amdgcn_s_memtime() - st_first);                                 \
+            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                    \
+            atomicAdd(c_ + 13, r_ - st_real);                                                            \
+            atomicMax(c_ + 14, (1ull << 62) - st_real);                                                  \
+            atomicMax(c_ + 15, r_);                                                                      \
+        }                                                                                                \
+    } while (0)
+#endif
+#else
+#define ISTAMP_DECL
+#define ISTAMP(k)
+#define ISTAMP_BIG(it, big)
+#define ISTAMP_END(iters)
+#endif
+
