@@ -260,11 +260,12 @@ struct OccRule {
     __device__ __forceinline__ uint32_t value(uint32_t p, uint32_t h) const
     {
         if ((p | h) == 0) return 50u;
-        if (h >= (uint32_t)hit_levels) return 100u;
-        uint32_t t = pass_thresh[0];
+        // (as a sum of per-level tests with constant table indices: written as a select chain over the table the
+        // compiler turns it into a per-lane indexed load from a private copy, i.e. scratch memory)
+        bool occ = h >= (uint32_t)hit_levels;
 #pragma unroll
-        for (int k = 1; k < kMaxHitLevels; ++k) t = (h == (uint32_t)k) ? pass_thresh[k] : t;
-        return p >= t ? 100u : 0u;
+        for (int k = 0; k < kMaxHitLevels; ++k) occ |= (h == (uint32_t)k) & (p >= pass_thresh[k]) & (k < hit_levels);
+        return occ ? 100u : 0u;
     }
 };
 
@@ -1602,13 +1603,9 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
                              hipStream_t s)
 {
     const size_t lds_max = win_lds_bytes(kWinMaxGroup, kMaxSortRays, kWinCells);
-    static bool attr_done[2] = {false, false};
-    constexpr int which = std::is_same<Src, ReplaySource>::value ? 0 : 1;
-    if (!attr_done[which]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_update_win<Src>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    {
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_update_win<Src>), (int)lds_max);
         if (e != hipSuccess) return e;
-        attr_done[which] = true;
     }
     int groups = (scans + group - 1) / group;
     long rays = (long)group * n;
@@ -1629,14 +1626,10 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     // one scan per map, cast by the map's only writer, live pmap, the reference's one-hit-occupies rule
     if (exclusive && group == 1 && scans == 1 && g.hit_levels == 1 && (g.yw & 15) == 0 && (((size_t)g.xw * g.yw) & 3) == 0 &&
         g.yw <= win_cells && n <= kOwnerMaxRays * kOwnerThreads) {
-        static bool own_attr[2] = {false, false};
-        if (!own_attr[which]) {
-            for (const void *f : {reinterpret_cast<const void *>(&k_grid_update_owner<Src, 1>), reinterpret_cast<const void *>(&k_grid_update_owner<Src, 2>),
-                                  reinterpret_cast<const void *>(&k_grid_update_owner_redo<Src, 1>)}) {
-                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-                if (e != hipSuccess) return e;
-            }
-            own_attr[which] = true;
+        for (const void *f : {reinterpret_cast<const void *>(&k_grid_update_owner<Src, 1>), reinterpret_cast<const void *>(&k_grid_update_owner<Src, 2>),
+                              reinterpret_cast<const void *>(&k_grid_update_owner_redo<Src, 1>)}) {
+            hipError_t e = allow_dynamic_lds(f, (int)lds_max);
+            if (e != hipSuccess) return e;
         }
         const size_t lds = win_lds_bytes(1, sort_cap, win_cells);
         // the plain case (all of a closed room's scans) goes through the byte-window kernel, three workgroups per CU;
@@ -2035,12 +2028,9 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
     hipLaunchKernelGGL((k_ray_bits<Src>), dim3(scans, L), dim3(256), 0, s, g, src, ts, G);
     const int tiles_x = (g.xw + kTileSide - 1) / kTileSide, tiles_y = (g.yw + kTileSide - 1) / kTileSide;
     size_t lds = (size_t)kTileSide * ((kTileSide / 2) | 1) * 4 + kLdsGuard;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_cast),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_tile_cast), (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     // 1024 lanes: the kernel is bound by the latency of its loads and LDS atomics (measured 2.35 ms
     // with 512, 2.14 ms with 1024 on the 1080-beam / 2000x2000 replay; tiles of 128 or 224 cells are slower)

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <string>
 #include <initializer_list>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "slam_internal.h"
@@ -111,7 +113,24 @@ struct slam_grid {
     bool live_dirty = false;       // pmap_live is behind the counters
 };
 
-namespace slam { thread_local LaunchTimer g_launch_timer = {nullptr, nullptr}; }
+namespace slam {
+thread_local LaunchTimer g_launch_timer = {nullptr, nullptr};
+
+hipError_t allow_dynamic_lds(const void *kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> done;       // (device, kernel) pairs that have the attribute
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == dev && d.second == kernel) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.emplace_back(dev, kernel);
+    return e;
+}
+}  // namespace slam
 
 namespace {
 

@@ -38,6 +38,10 @@ inline bool launch_events(hipEvent_t *e0, hipEvent_t *e1)
     } while (0)
 
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remembered per (device, function), so a
+// second device used by the same process gets the attribute too.
+hipError_t allow_dynamic_lds(const void *kernel, int bytes);
+
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;            // 1024-thread workgroups
 constexpr int kMaxRayCells = 1 << 20;    // longest ray the grid kernels will walk (cells)

@@ -56,6 +56,9 @@ sys.path.insert(0, ROOT)
 PKG = "a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# what this chip delivers for mixed read + write traffic (tools/ubench_rmw.hip, profiles/r03_ubench_rmw.txt): streaming copy
+# 4.5 TB/s, counters read and written back in place with non-temporal loads and stores 4.75 TB/s (reads alone 6.3, writes alone 4.4)
+MIXED_RW_PEAK_GBS = 4750.0
 F64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector (half the 157.3 TF FP32 vector rate)
 # f64 VALU issue: 256 CUs x 4 SIMDs, one wave64 f64 instruction per 4 cycles per SIMD at 2.4 GHz
 F64_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
@@ -100,6 +103,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run comparison with the oracle")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the one-lane repeat of the measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="default config only: skip the brief particles / dense runs behind it")
     ap.add_argument("--sustain-seconds", type=float, default=0.5)
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the parity block is always on)")
     args = ap.parse_args()
@@ -184,6 +188,18 @@ def cpu_baseline_particles(wl, args, budget_s):
             "sample": "first %d of %d particle hypotheses (%.1f s), C port of the reference, one thread per particle" % (done, wl.P, t_used)}
 
 
+def source_hash():
+    """SHA-256 over the kernel sources of the library in this tree (csrc/*.hip, *.h), 16 hex digits: tools/summarize_profiles.py
+    stamps profiles/pmc_traffic.json with it, and a roofline built on PMC figures of OTHER sources says so (stale_pmc)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(config, kernel):
     """Per-launch PMC figures of `kernel` from the committed rocprofv3 --pmc summaries, if any
     (profiles/pmc_traffic.json: {config: {kernel: {...}}}; produced by tools/profile_gpu.sh)."""
@@ -194,6 +210,10 @@ def load_pmc(config, kernel):
     d = d.get(config, d if config == "replay" else {})
     if not isinstance(d, dict):
         return {}
+    stamp = d.get("_source_hash")
+    stale = None
+    if stamp != source_hash():
+        stale = "profiles/pmc_traffic.json[%s] was collected on kernel sources %s, this tree is %s: re-run tools/profile_gpu.sh" % (config, stamp, source_hash())
     if "+" in kernel:          # a family of kernels launched back to back: byte and instruction counts add up
         parts = [d.get(k, {}) for k in kernel.split("+")]
         if not all(parts):
@@ -201,8 +221,14 @@ def load_pmc(config, kernel):
         out = {"source": parts[0].get("source")}
         for key in ("hbm_bytes_per_launch", "valu_insts_per_launch", "lds_insts_per_launch"):
             out[key] = sum(p.get(key) or 0.0 for p in parts)
-        return out
-    return d.get(kernel, {})
+        for key in ("valu_busy_frac", "issue_mix", "valu_insts_per_launch_qpt3"):      # of the family's main kernel
+            if parts[0].get(key) is not None:
+                out[key] = parts[0][key]
+    else:
+        out = dict(d.get(kernel, {}))
+    if out and stale:
+        out["stale"] = stale
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -210,7 +236,7 @@ def load_pmc(config, kernel):
 # --------------------------------------------------------------------------------------
 class ReplayWorkload:
     """configs[1] / [3] / [4]: per lane a DeviceReplay + map + pmap; a step runs on lane slot % lanes."""
-    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
+    family_kernels = {"icp": "k_icp+k_icp_exact", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args
@@ -302,13 +328,22 @@ class ReplayWorkload:
     def cpu_baseline(self, budget):
         return cpu_baseline_replay(self.rep, self.args, budget)
 
+    def close(self):
+        """Free the maps, contexts and device buffers now (another configuration follows in the same process)."""
+        for ln in self.lanes:
+            ln.dr.ctx.synchronize()
+            ln.grid.close()
+            ln.dr.grid = None
+            ln.dr.ctx.close()
+        self.lanes, self.ring = [], None
+
 
 class ParticleWorkload:
     """configs[2]: slam_particles_dev on P hypotheses; maps persist (no reset), live pmap.  With several lanes
     consecutive steps (independent: the same scan pair, the same priors) alternate between contexts that each
     own a stream, output buffers and a set of P maps, so that one step's scan matching (vector-issue bound)
     shares the chip with another's ray cast (memory bound)."""
-    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_owner", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
+    family_kernels = {"icp": "k_icp+k_icp_exact", "grid": "k_grid_update_owner8+k_grid_update_owner_redo", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args
@@ -398,50 +433,44 @@ class ParticleWorkload:
     def cpu_baseline(self, budget):
         return cpu_baseline_particles(self, self.args, budget)
 
+    def close(self):
+        for ln in self.lanes:
+            ln.ctx.synchronize()
+            ln.grid.close()
+            ln.ctx.close()
+        self.lanes, self.shared, self.t, self.grid, self.ctx = [], None, None, None, None
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or unset WORLD_SIZE and "
-              "let bench.py start the ranks)" % (args.gpus, world, args.gpus), file=sys.stderr)
-        sys.exit(2)
-    # Each lane's stream should own a hardware queue (the HIP runtime multiplexes streams onto
-    # GPU_MAX_HW_QUEUES queues, 4 by default): with a process group RCCL adds streams of its own,
-    # and two lanes sharing a queue serialise (measured 0.26 instead of 0.18 ms per step).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    import importlib
-    import torch
-    dist = None
-    # under torch.distributed.run (RANK and MASTER_ADDR set) the collective path is taken even
-    # for one rank, so that it can be rehearsed on a one-GPU box
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
-    if use_dist:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout
-        # for the ONE JSON line (the banner goes to stderr instead)
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
-    slam = importlib.import_module(PKG)
+
+class Env:
+    """What a measurement needs besides its arguments: the package, torch, the process group."""
+    def __init__(self, slam, torch, dist, rank, world, local, use_dist):
+        self.slam, self.torch, self.dist = slam, torch, dist
+        self.rank, self.world, self.local, self.use_dist = rank, world, local, use_dist
+
+
+def config_args(base, name):
+    """Arguments of another --config with that config's defaults (sizes, lanes, steps), everything else as given."""
+    a = argparse.Namespace(**vars(base))
+    cfg = CONFIGS[name]
+    a.config = name
+    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
+        setattr(a, k, cfg[k])
+    a.scans = cfg["scans"]
+    a.steps, a.warmup = (48, 5) if name == "replay" else (12, 2)
+    a.grid_group = 0
+    a.icp_qpt = None
+    return a
+
+
+def measure(args, env, collective=True, want_single=True, want_sustained=True):
+    """One workload of --config: warm-up, the timed K steps (barrier + synchronize on both sides, MAX over ranks),
+    the sustained continuation, the one-lane repeat.  Returns a dict of raw results; nothing is printed."""
+    slam, torch, dist = env.slam, env.torch, env.dist
+    use_dist = env.use_dist and collective
+    world = env.world if use_dist else 1
     slots = args.steps + args.warmup
     Workload = ParticleWorkload if args.config == "particles" else ReplayWorkload
-    wl = Workload(slam, torch, args, rank, local, args.lanes, slots)
+    wl = Workload(slam, torch, args, env.rank, env.local, args.lanes, slots)
     dev = wl.dev
     gathered = torch.empty((slots, world * 3), dtype=torch.float64, device=dev) if use_dist else None
     gathered_all = torch.empty(world * slots * 3, dtype=torch.float64, device=dev) if use_dist else None
@@ -459,26 +488,26 @@ def main():
 
     marks = {}
 
-    def fence(w=wl, collective=True):
+    def fence(w=wl, coll=True):
         for c in w.contexts():
             c.synchronize()                # joins the lane's compose / map streams
         marks["drained"] = time.perf_counter()
-        if use_dist and args.gather == "end" and collective:
+        if use_dist and args.gather == "end" and coll:
             dist.all_gather_into_tensor(gathered_all, w.final_poses(slots))
         torch.cuda.synchronize()
-        if use_dist and collective:
+        if use_dist and coll:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(w, steps, collective=True):
-        """Time exactly `steps` steps of workload w; returns (elapsed, enqueue, {family: [ms, launches]})."""
+    def timed(w, steps, coll=True):
+        """Time exactly `steps` steps of workload w; returns (elapsed, enqueue, {family: [ms, launches]}, t0)."""
         for c in w.contexts():
             c.timing_enable(not args.no_timing)
         t0 = time.perf_counter()
         for _ in range(steps):
             step(w)
         enqueue = time.perf_counter() - t0     # host time to enqueue all steps (launch-bound if ~ elapsed)
-        fence(w, collective)
+        fence(w, coll)
         elapsed = time.perf_counter() - t0
         fam = {}
         for c in w.contexts():                 # HIP-event times per kernel family
@@ -501,48 +530,45 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_ranks = dist.get_world_size() if use_dist else 1
-    value = wl.units_per_step * n_ranks * args.steps / elapsed
-    dev_results = wl.collect()
-
+    res = {"wl": wl, "elapsed": elapsed, "elapsed_local": elapsed_local, "enqueue": enqueue, "fam": fam, "closing_ms": closing_ms,
+           "n_ranks": world, "dev_results": wl.collect(), "single": None, "sustained": None}
     if args.no_timing:
-        if rank == 0:
-            print(json.dumps({"value": value, "ms_per_step": elapsed / args.steps * 1e3, "lanes": args.lanes,
-                              "pipeline": args.pipeline, "note": "experiment without HIP-event timing"}), flush=True)
-        if use_dist:
-            dist.destroy_process_group()
-        return
+        return res
 
-    # ---- the same workload, run on past the contract's K steps until >= --sustain-seconds ----
-    sustained = None
-    if args.sustain_seconds > 0 and not use_dist:
+    # ---- sustained: the same workload stepped on past the contract's K steps until >= --sustain-seconds have
+    #      passed, with the kernels' HIP-event times kept (the driver's K steps last a few milliseconds: all lanes
+    #      start in the scan-matching phase and end in the map phase, which the longer run averages out) ----------
+    if want_sustained and args.sustain_seconds > 0:
         per = elapsed / args.steps
         more = int(min(max(args.sustain_seconds / per, 1), 200000))
-        for c in wl.contexts():
-            c.timing_enable(False)
+        more -= more % max(len(wl.contexts()), 1) if more > len(wl.contexts()) else 0     # no lane runs a step more than another
         ts = time.perf_counter()
-        for _ in range(more):
-            step()
-        fence(collective=False)
-        dt = time.perf_counter() - ts
-        sustained = {"steps": more, "seconds": dt, "value": wl.units_per_step * more / dt, "ms_per_step": dt / more * 1e3}
+        dt, _, fam_s, _ = timed(wl, more, coll=False)
+        res["sustained"] = {"steps": more, "seconds": dt, "value": wl.units_per_step * more / dt, "ms_per_step": dt / more * 1e3,
+                            "kernel_ms_per_launch_overlapped": {k: v[0] / v[1] for k, v in fam_s.items() if v[1] > 0},
+                            "note": "same workload, same lanes, stepped on for >= %.1f s; per-GPU figure (no collective inside)" % args.sustain_seconds}
 
     # ---- single stream: one lane, kernels back to back (their stand-alone durations) ----------
-    single = None
-    if not args.no_single_stream and len(wl.contexts()) > 1 and not use_dist:
-        w1 = Workload(slam, torch, args, rank, local, 1, slots)
+    if want_single and len(wl.contexts()) > 1:
+        w1 = Workload(slam, torch, args, env.rank, env.local, 1, slots)
         for _ in range(args.warmup):
             step(w1)
-        fence(w1, collective=False)
-        e1, _, fam1, _ = timed(w1, args.steps, collective=False)
-        single = {"lanes": 1, "ms_per_step": e1 / args.steps * 1e3, "value": w1.units_per_step * args.steps / e1,
-                  "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam1.items() if v[1] > 0}}
+        fence(w1, coll=False)
+        e1, _, fam1, _ = timed(w1, args.steps, coll=False)
+        res["single"] = {"lanes": 1, "ms_per_step": e1 / args.steps * 1e3, "value": w1.units_per_step * args.steps / e1,
+                         "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam1.items() if v[1] > 0}}
+        w1.close()
         del w1
     elif len(wl.contexts()) == 1:
-        single = {"lanes": 1, "ms_per_step": elapsed_local / args.steps * 1e3, "value": wl.units_per_step * args.steps / elapsed_local,
-                  "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam.items() if v[1] > 0}, "note": "the main measurement is single-stream"}
+        res["single"] = {"lanes": 1, "ms_per_step": elapsed_local / args.steps * 1e3, "value": wl.units_per_step * args.steps / elapsed_local,
+                         "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam.items() if v[1] > 0}, "note": "the main measurement is single-stream"}
+    return res
 
-    # ---- roofline of the dominant kernel (largest share of the HIP-event time) -----------
+
+def roofline_of(args, res):
+    """The "roofline" object of the JSON line from a measurement's raw results (dominant kernel = largest share of the
+    HIP-event time; its duration is the stand-alone one-lane duration wherever one was measured)."""
+    wl, fam, single, elapsed = res["wl"], res["fam"], res["single"], res["elapsed"]
     ms = {k: v[0] for k, v in fam.items() if v[1] > 0}
     dom = max(ms, key=ms.get)
     dom_ms, dom_n = fam[dom]
@@ -553,6 +579,14 @@ def main():
     avg_ms = dom_ms / dom_n
     alone_ms = single["kernel_ms_per_launch"].get(dom, avg_ms) if single else avg_ms
     pmc = load_pmc(args.config, kname)
+    profiled_units = CONFIGS[args.config]["scans"] - 1 if args.config != "particles" else wl.units_per_step
+    if pmc and wl.units_per_step != profiled_units:
+        # the PMC passes ran the configuration's default size: counts per launch scale with the scans per launch
+        scale = wl.units_per_step / float(profiled_units)
+        for key in ("hbm_bytes_per_launch", "valu_insts_per_launch", "lds_insts_per_launch"):
+            if pmc.get(key):
+                pmc[key] = pmc[key] * scale
+        pmc["source"] = "%s, scaled x%.3f to %d scans per launch" % (pmc.get("source"), scale, wl.units_per_step)
     hbm = {"achieved": alg.get(dom, 0) / (alone_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "algorithmic_bytes_per_launch": alg.get(dom, 0)}
     hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
@@ -566,9 +600,22 @@ def main():
         roofline = {"kernel": kname, "bound": "valu_f64_issue", "achieved": ach, "peak": F64_ISSUE_PEAK, "unit": "wave-instructions/s",
                     "frac": ach / F64_ISSUE_PEAK if ach else pmc.get("valu_busy_frac"), "traffic": traffic,
                     "valu_busy_frac_pmc": pmc.get("valu_busy_frac"), "hbm": hbm,
-                    "note": "achieved = SQ_INSTS_VALU per launch (profiles/, same command) / stand-alone launch duration measured live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per f64 wave instruction"}
+                    "note": "achieved = SQ_INSTS_VALU per launch (profiles/, same command) / stand-alone launch duration measured live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per f64 wave instruction (an upper bound of the issue time: the non-f64 share of the instructions issues in 2 cycles, see issue_mix)"}
+        mix = pmc.get("issue_mix")
+        if mix and insts:
+            # the honest peak: f64 instructions hold a SIMD for 4 cycles, the others for 2 (SIMD-32); static ISA mix of the shipped kernel
+            cyc = insts * (4.0 * mix["f64_share"] + 2.0 * (1.0 - mix["f64_share"]))
+            roofline["issue_mix"] = dict(mix, issue_cycles_per_launch=cyc, frac_of_issue_cycles=cyc / (alone_ms * 1e-3 * 1024 * 2.4e9))
     else:
         roofline = dict(hbm, kernel=kname, bound="hbm", traffic=traffic)
+        if traffic and alone_ms:
+            # what the chip delivers for this kind of traffic (tools/ubench_rmw.hip, profiles/): counters read and written
+            # back in place; the physical rate is the counter-measured bytes over the same duration
+            roofline["physical"] = {"achieved": traffic / (alone_ms * 1e-3) / 1e9, "unit": "GB/s", "traffic_over_algorithmic": traffic / max(alg.get(dom, 0), 1),
+                                    "mixed_rw_peak_measured": MIXED_RW_PEAK_GBS,
+                                    "frac_of_mixed_rw_peak": traffic / (alone_ms * 1e-3) / 1e9 / MIXED_RW_PEAK_GBS}
+    if pmc.get("stale"):
+        roofline["stale_pmc"] = pmc["stale"]
     roofline.update({"traffic_source": pmc.get("source"), "avg_launch_ms": alone_ms, "avg_launch_ms_overlapped": avg_ms, "launches": dom_n,
                      "kernel_ms_per_launch_overlapped": {k: fam[k][0] / fam[k][1] for k in ms},
                      "timed": "start/stop HIP events carried by every dispatch of all %d lanes; avg_launch_ms is the one-lane (stand-alone) duration, "
@@ -602,7 +649,7 @@ def main():
         roofline["icp_work"] = {"exhaustive_equivalent_distance_evals_per_s": evals / icp_s, "mean_iters": float(iters.mean()),
                                 "note": "equivalent brute-force rate; f64 VALU peak is %.1f TFLOP/s (~%.1e evals/s at 6 flop each)"
                                         % (F64_VALU_PEAK_TFLOPS, F64_VALU_PEAK_TFLOPS * 1e12 / 6)}
-        lds_insts = load_pmc(args.config, "k_icp").get("lds_insts_per_launch")
+        lds_insts = load_pmc(args.config, "k_icp+k_icp_exact").get("lds_insts_per_launch")
         if lds_insts:
             roofline["icp_work"]["lds"] = {"wave_instructions_per_launch": lds_insts, "upper_bound_GBps": lds_insts * 1024.0 / icp_s / 1e9,
                                            "peak_GBps": 256 * 128 * 2.4,
@@ -611,18 +658,25 @@ def main():
         grid_s = ((single["kernel_ms_per_launch"].get("grid") if single else None) or fam["grid"][0] / fam["grid"][1]) * 1e-3
         roofline["grid_cast"] = {"cell_visits_per_step": wl.visits, "visits_per_s": wl.visits / grid_s,
                                  "algorithmic_GBps": 9 * wl.visits / grid_s / 1e9, "frac_of_hbm_peak": 9 * wl.visits / grid_s / 1e9 / HBM_PEAK_GBS}
+    return roofline
 
+
+def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, workload, units_per_step, lanes, roofline, use_dist,
+                  single=None, sustained=None, parity=None, cpu_baseline=None, other_configs=None, single_gpu_same_workload=None,
+                  rccl_world_size=None):
+    """The ONE JSON line (a dict) from measured numbers.  Pure: tests/test_bench_cpu.py checks the schema of the N = 1
+    and N > 1 lines with made-up measurements."""
     out = {
         "metric": "scans/sec (360-beam ICP + 0.05 m grid update)" if args.config != "dense" else "scans/sec (1080-beam ICP + 0.02 m grid update)",
         "value": value, "unit": "scans/s",
-        "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
+        "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "host_enqueue_ms_per_step": enqueue_ms,
         "closing_collectives_ms": closing_ms,   # all_gather + barrier after the last replay
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wl.workload_name(), "name": args.config,
-                   "units_per_step_per_gpu": wl.units_per_step, "point_buffers": args.points,
+        "config": {"workload": workload, "name": args.config,
+                   "units_per_step_per_gpu": units_per_step, "point_buffers": args.points,
                    "point_buffers_note": "storage type of the points the scan matcher sees (arithmetic is float64 either way)",
-                   "pipeline": args.pipeline, "lanes": len(wl.contexts()), "grid_mode": args.grid_mode, "grid_group": args.grid_group,
+                   "pipeline": args.pipeline, "lanes": lanes, "grid_mode": args.grid_mode, "grid_group": args.grid_group,
                    "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
         "roofline": roofline,
     }
@@ -630,11 +684,136 @@ def main():
         out["single_stream"] = single
     if sustained:
         out["sustained"] = sustained
-    if rank == 0 and not args.no_parity:
-        out["parity"] = wl.parity(dev_results)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+    if parity is not None:
+        out["parity"] = parity
+    if cpu_baseline is not None:
+        out["cpu_baseline"] = cpu_baseline
+    if other_configs:
+        out["other_configs"] = other_configs
+    if use_dist:
+        # N > 1 runs configs[3] (5 000-scan trajectories), N = 1 runs configs[1] (1 000 scans): the per-GPU rates differ by
+        # construction, so a scaling efficiency is value / (n_gpus x single_gpu_same_workload.value), not value / (n x the N = 1 line)
+        out["rccl_world_size"] = rccl_world_size
+        out["single_gpu_same_workload"] = single_gpu_same_workload
+        if single_gpu_same_workload and single_gpu_same_workload.get("value"):
+            out["scaling_efficiency_same_workload"] = value / (n_ranks * single_gpu_same_workload["value"])
+    return out
+
+
+def other_config_summary(args, res, roofline, parity):
+    """What the default line carries of another configuration (bench.py --config <name> prints its full line)."""
+    r = {"value": res["wl"].units_per_step * args.steps / res["elapsed"], "unit": "scans/s", "ms_per_step": res["elapsed"] / args.steps * 1e3,
+         "steps": args.steps, "warmup": args.warmup, "lanes": len(res["wl"].contexts()), "workload": res["wl"].workload_name(),
+         "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "physical", "stale_pmc") if k in roofline},
+         "parity": parity}
+    if res["single"]:
+        r["single_stream"] = res["single"]
+    if res["sustained"]:
+        r["sustained"] = {k: res["sustained"][k] for k in ("value", "ms_per_step", "steps")}
+    return r
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or unset WORLD_SIZE and "
+              "let bench.py start the ranks)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    # Each lane's stream should own a hardware queue (the HIP runtime multiplexes streams onto
+    # GPU_MAX_HW_QUEUES queues, 4 by default): with a process group RCCL adds streams of its own,
+    # and two lanes sharing a queue serialise (measured 0.26 instead of 0.18 ms per step).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import importlib
+    import torch
+    dist = None
+    # under torch.distributed.run (RANK and MASTER_ADDR set) the collective path is taken even
+    # for one rank, so that it can be rehearsed on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    slam = importlib.import_module(PKG)
+    same_workload = None
+    if use_dist:
+        torch.cuda.set_device(local)
+        # BEFORE the process group exists: rank 0 times its own share of the N-GPU workload alone (same scans, same lanes,
+        # no collective), so that the line carries the one-GPU figure of the SAME workload (VERDICT r2 #6)
+        if rank == 0 and not args.no_timing:
+            env1 = Env(slam, torch, None, 0, 1, local, False)
+            r1 = measure(args, env1, collective=False, want_single=True, want_sustained=False)
+            same_workload = {"value": r1["wl"].units_per_step * args.steps / r1["elapsed"], "unit": "scans/s", "ms_per_step": r1["elapsed"] / args.steps * 1e3,
+                             "workload": r1["wl"].workload_name(), "single_stream": r1["single"],
+                             "note": "rank 0 alone, before init_process_group: the same 5 000-scan trajectory, lanes and steps"}
+            same_single = r1["single"]
+            r1["wl"].close()
+            del r1
+            torch.cuda.empty_cache()
+        import torch.distributed as dist
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout
+        # for the ONE JSON line (the banner goes to stderr instead)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    env = Env(slam, torch, dist, rank, world, local, use_dist)
+    res = measure(args, env, want_single=not args.no_single_stream and not use_dist, want_sustained=not use_dist)
+    wl = res["wl"]
+    n_ranks = dist.get_world_size() if use_dist else 1
+    value = wl.units_per_step * n_ranks * args.steps / res["elapsed"]
+
+    if args.no_timing:
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": res["elapsed"] / args.steps * 1e3, "lanes": args.lanes,
+                              "pipeline": args.pipeline, "note": "experiment without HIP-event timing"}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    if use_dist and same_workload and rank == 0:
+        res["single"] = same_single          # stand-alone kernel durations of the same workload: roofline.frac keeps its meaning under a process group
+    roofline = roofline_of(args, res)
+    parity = wl.parity(res["dev_results"]) if rank == 0 and not args.no_parity else None
+    cpu = wl.cpu_baseline(args.cpu_seconds) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
+    single, sustained = res["single"], res["sustained"]
+
+    # ---- the other single-GPU configurations of BASELINE.json, briefly, in the same process (outside every timed region
+    #      above): configs[2] (particles) and configs[4] (dense), each with its own roofline and parity block ----------
+    others = None
+    if args.config == "replay" and not use_dist and not args.no_other_configs and rank == 0:
+        res["workload_name"], res["units"], res["lanes"] = wl.workload_name(), wl.units_per_step, len(wl.contexts())
+        wl.close()
+        del res["wl"], wl
+        torch.cuda.empty_cache()
+        others = {}
+        for name in ("particles", "dense"):
+            a2 = config_args(args, name)
+            try:
+                r2 = measure(a2, env, want_single=True, want_sustained=False)
+                others[name] = other_config_summary(a2, r2, roofline_of(a2, r2), None if args.no_parity else r2["wl"].parity(r2["dev_results"]))
+                r2["wl"].close()
+                del r2
+            except Exception as e:                      # the headline line must not die of a secondary configuration
+                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        wl_name, units, lanes = res["workload_name"], res["units"], res["lanes"]
     if rank == 0:
+        if others is None:
+            wl_name, units, lanes = wl.workload_name(), wl.units_per_step, len(wl.contexts())
+        out = assemble_line(args, n_ranks, value, res["elapsed"] / args.steps * 1e3, res["enqueue"] / args.steps * 1e3, res["closing_ms"],
+                            wl_name, units, lanes, roofline, use_dist, single=single, sustained=sustained, parity=parity, cpu_baseline=cpu,
+                            other_configs=others, single_gpu_same_workload=same_workload,
+                            rccl_world_size=n_ranks if use_dist else None)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

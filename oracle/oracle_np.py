@@ -109,16 +109,19 @@ def collapsed(rows):
     return rows.shape[0] > 0 and bool(np.all(rows == rows[0]))
 
 
-def get_transform(src, tar):
+def get_transform(src, tar, collapsed_rule="canonical"):
     """W12m/icp.py:149-179.  src, tar [N,2] paired rows -> T 3x3.  Uses the
     ``Vt[1,:]`` reflection fix of the W12 generation (:168); W7/icp.py:136 indexes
-    ``Vt[2,:]`` and cannot run."""
+    ``Vt[2,:]`` and cannot run.  ``collapsed_rule="reference"`` is the reference's own
+    arithmetic on collapsed sets too (the SVD of its rounding noise, see collapsed()):
+    the mode that keeps this restatement independent of the documented deviation and is
+    checked against tests/golden/g8_collapsed.npz."""
     centroid_a = np.mean(src, axis=0)
     centroid_b = np.mean(tar, axis=0)
     aa = src - centroid_a
     bb = tar - centroid_b
     w = np.dot(bb.transpose(), aa)
-    if collapsed(src) or collapsed(tar):
+    if collapsed_rule != "reference" and (collapsed(src) or collapsed(tar)):
         w = np.zeros((2, 2))          # documented canonical answer, see collapsed()
     u, _s, vt = np.linalg.svd(w)
     r = np.dot(u, vt)

@@ -43,3 +43,41 @@ def test_gpus_world_size_mismatch_fails_loudly():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
                          env=env, timeout=120)
     assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and out.stdout.strip() == ""
+
+
+def _fake_args(**kw):
+    import argparse
+    d = dict(config="replay", steps=20, warmup=5, points="f64", pipeline=0, grid_mode=1, grid_group=0, gather="end", gpus=1)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_json_line_schema_single_and_multi_gpu():
+    """The JSON line is assembled by a pure function: with made-up measurements the N = 1 line carries the contract's
+    keys plus roofline / cpu_baseline / other_configs, and the N > 1 line carries what makes it comparable with one
+    GPU: the one-GPU figure of the SAME 5 000-scan workload, the RCCL world size, and stand-alone
+    kernel durations behind roofline.frac."""
+    sys.path.insert(0, ROOT)
+    import bench
+    roof = {"kernel": "k_icp", "bound": "valu_f64_issue", "achieved": 2.8e11, "peak": 6.1e11, "unit": "wave-instructions/s", "frac": 0.46, "traffic": 3.5e6}
+    one = bench.assemble_line(_fake_args(), 1, 8.5e6, 0.118, 0.05, 0.2, "configs[1]: ...", 999, 4, roof, False,
+                              single={"lanes": 1, "ms_per_step": 0.26, "value": 3.8e6, "kernel_ms_per_launch": {"icp": 0.12}},
+                              sustained={"steps": 4000, "seconds": 0.5, "value": 9.8e6, "ms_per_step": 0.1, "kernel_ms_per_launch_overlapped": {"icp": 0.23}},
+                              parity={"iters_equal": True}, cpu_baseline={"value": 3000.0, "unit": "scans/s", "cores": 64, "kind": "port", "sample": "..."},
+                              other_configs={"particles": {"value": 7.6e6, "roofline": {"frac": 0.34, "traffic": 3.1e9}, "parity": {}},
+                                             "dense": {"value": 8.5e5, "roofline": {"frac": 0.38, "traffic": 3.8e9}, "parity": {}}})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity", "single_stream", "sustained", "other_configs"):
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["vs_baseline"] is None and one["config"]["workload"].startswith("configs[1]")
+    assert set(one["other_configs"]) == {"particles", "dense"} and "kernel_ms_per_launch_overlapped" in one["sustained"]
+    assert "single_gpu_same_workload" not in one and "rccl_world_size" not in one
+    same = {"value": 9.0e6, "unit": "scans/s", "ms_per_step": 0.55, "workload": "configs[3] share: ...",
+            "single_stream": {"lanes": 1, "kernel_ms_per_launch": {"icp": 0.6}}}
+    many = bench.assemble_line(_fake_args(gpus=8, steps=12, warmup=2), 8, 6.8e7, 0.59, 0.1, 0.3, "configs[3] share: ...", 4999, 4, roof, True,
+                               single=same["single_stream"], single_gpu_same_workload=same, rccl_world_size=8)
+    for k in ("single_gpu_same_workload", "rccl_world_size", "scaling_efficiency_same_workload", "single_stream", "roofline"):
+        assert k in many, k
+    assert many["n_gpus"] == 8 and many["rccl_world_size"] == 8 and many["config"]["workload"].startswith("configs[3]")
+    assert abs(many["scaling_efficiency_same_workload"] - 6.8e7 / (8 * 9.0e6)) < 1e-12
+    assert "all_gather" in many["config"]["parallelism"] and many["single_stream"]["kernel_ms_per_launch"]["icp"] == 0.6

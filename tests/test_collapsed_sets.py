@@ -37,6 +37,27 @@ def test_reference_answer_is_an_arbitrary_rotation_about_the_same_fixed_point(g8
     assert np.ptp(angles) > 90.0                                             # "arbitrary": all over the circle
 
 
+def test_reference_faithful_mode_reproduces_the_reference(g8):
+    """The NumPy restatement WITHOUT the canonical rule is the reference's own arithmetic: it returns what the
+    reference returned (G8), so the restatement stays an independent check of W12m/icp.py:154-169 and the deviation
+    is exactly the one rule.  Reference and canonical answer agree on where the source centroid goes."""
+    for k in range(len(g8["src"])):
+        src, rows, T_ref = g8["src"][k], g8["tar_rows"][k], g8["T_ref"][k]
+        # (the memory layouts the reference saw - a transposed view and a fancy-indexed copy, oracle/gen_golden.py gen_g8:
+        # np.mean sums a strided view in another order than a contiguous array, and here the answer IS that rounding)
+        tar_rows = np.ascontiguousarray(rows.T)
+        T = on.get_transform(src.T, tar_rows, collapsed_rule="reference")
+        assert np.max(np.abs(T - T_ref)) < 1e-9, k
+        Tc = on.get_transform(src.T, tar_rows)
+        ca = src.mean(axis=1)
+        assert np.max(np.abs((T[:2, :2] @ ca + T[:2, 2]) - (Tc[:2, :2] @ ca + Tc[:2, 2]))) < 1e-9
+        assert np.max(np.abs(T[:2, :2] - Tc[:2, :2])) > 0.1                   # ... and differ in the rotation
+    # on sets that are NOT collapsed the two modes are the same function
+    rng = np.random.default_rng(5)
+    a, b = rng.normal(0, 3, size=(40, 2)), rng.normal(0, 3, size=(40, 2))
+    assert np.array_equal(on.get_transform(a, b), on.get_transform(a, b, collapsed_rule="reference"))
+
+
 def test_oracles_return_the_canonical_answer(g8):
     for k in range(len(g8["src"])):
         src, rows = g8["src"][k], g8["tar_rows"][k]

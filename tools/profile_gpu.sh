@@ -6,7 +6,7 @@
 # under gpurun_out/prof_<tag>_<config>/profiles/ - copy them into profiles/ and commit).
 #  1. --kernel-trace --stats of the default bench command of that config (replay: 4 lanes,
 #     durations include overlap)
-#  2. replay only: the same for one lane (kernels back to back: their stand-alone durations)
+#  2. the same for one lane (kernels back to back: their stand-alone durations)
 #  3. --pmc passes, ONE counter group per run and nothing else enabled (the pool refuses
 #     --pmc combined with other trace domains), one lane.
 set -u
@@ -21,15 +21,14 @@ case $CFG in
   replay) STEPS="--steps 48 --warmup 5"; PSTEPS="--steps 5 --warmup 1";;
   *)      STEPS="--steps 12 --warmup 2"; PSTEPS="--steps 3 --warmup 1";;
 esac
-COMMON="--config $CFG --no-cpu-baseline --no-single-stream --sustain-seconds 0"
+COMMON="--config $CFG --no-cpu-baseline --no-single-stream --no-other-configs --sustain-seconds 0"
 # shellcheck disable=SC2086
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 "$R/bench.py" $COMMON $STEPS \
     > "$OUT/bench_default_under_rocprof.json" 2> "$OUT/trace_default.err" || { echo "kernel trace (default) failed"; tail -5 "$OUT/trace_default.err"; exit 1; }
-if [ "$CFG" = replay ]; then
+# one lane, every configuration: kernels back to back, i.e. the stand-alone durations the rooflines are priced with
 # shellcheck disable=SC2086
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1lane" -- python3 "$R/bench.py" $COMMON $STEPS --lanes 1 \
     > "$OUT/bench_1lane_under_rocprof.json" 2> "$OUT/trace_1lane.err" || { echo "kernel trace (1 lane) failed"; exit 1; }
-fi
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
@@ -47,5 +46,6 @@ if [ "$CFG" = replay ]; then
         > /dev/null 2>> "$OUT/pmc.err" || { echo "pmc pass 6 failed"; tail -5 "$OUT/pmc.err"; exit 1; }
     echo "SQ_INSTS_VALU icp_qpt=3" > "$OUT/pmc_6/counters.txt"
 fi
-python3 "$R/bench.py" --config $CFG $STEPS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
+[ "$CFG" = replay ] && python3 "$R/tools/isa_mix.py" "$OUT/isa_mix.json" > /dev/null
+python3 "$R/bench.py" --config $CFG --no-other-configs $STEPS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG" "$CFG"

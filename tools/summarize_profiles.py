@@ -114,6 +114,16 @@ def main():
             allcfg = {"replay": allcfg}
     except Exception:
         allcfg = {}
+    # the kernel sources these figures belong to (bench.py marks a roofline built on figures of other sources stale_pmc)
+    sys.path.insert(0, root)
+    try:
+        import bench
+        traffic["_source_hash"] = bench.source_hash()
+    except Exception as e:
+        traffic["_source_hash"] = "unknown (%s)" % e
+    mix = os.path.join(src, "isa_mix.json")
+    if os.path.exists(mix) and "k_icp" in traffic:
+        traffic["k_icp"]["issue_mix"] = json.load(open(mix))
     allcfg[cfg] = traffic
     json.dump(allcfg, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     if os.path.isdir(os.path.join(root, "profiles")) and os.access(os.path.join(root, "profiles"), os.W_OK):
