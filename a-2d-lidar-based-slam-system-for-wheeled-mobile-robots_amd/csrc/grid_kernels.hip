@@ -2039,21 +2039,372 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
     return hipGetLastError();
 }
 
+template <class Src>
+static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s);
+
 hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int L, int n_scan, int n, int group,
-                                    void *scratch, hipStream_t s)
+                                    void *scratch, hipStream_t s, int wedges)
 {
     if (n_scan < 2) return hipSuccess;
     ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
+    if (wedges) return launch_wedges(g, src, L, n_scan - 1, n, group, scratch, s);
     return launch_tiles(g, src, L, n_scan - 1, n, group, scratch, s);
 }
 
 // explicit world-frame endpoints (Mapping.update's own arguments), B scans into one map
 hipError_t launch_grid_update_tiles_explicit(const GridDev &g, const double *ox, const double *oy, const double *cx,
-                                             const double *cy, int B, int n, int group, void *scratch, hipStream_t s)
+                                             const double *cy, int B, int n, int group, void *scratch, hipStream_t s, int wedges)
 {
     ExplicitSource src{ox, oy, cx, cy, B, n};
+    if (wedges) return launch_wedges(g, src, 1, B, n, group, scratch, s);
     return launch_tiles(g, src, 1, B, n, group, scratch, s);
+}
+
+// ---------------------------------------------------------------------------------
+// Wedge ray casting for maps far larger than one LDS window (DESIGN.md "K4 wedges"): the rays of a group of
+// scans are dealt to workgroups by DIRECTION - steep or not, pointing up or down the walk axis, slope class - so
+// that a workgroup's rays fan out from (nearly) one origin inside a narrow wedge, and the wedge is swept in BANDS
+// along the walk axis: zero the window, walk every ray through the band, flush, next band.  A ray's walk
+// (bresenham.py:45-55) always ascends along its walk axis after the reference's endpoint swaps, which is the
+// band axis of its own steepness class: every ray is walked exactly ONCE, start to end, its state (step, y, float
+// error) resting in registers between bands - nothing is recorded, nothing re-entered.
+// The window of a band is a PARALLELOGRAM: rows follow the wedge with an integer shear M in {-1, 0, 1} per step
+// of the walk axis (the slope class's nearest integer), so the LDS index stays LINEAR in the cell,
+//     index = (a - a_lo) * ca + (y - M a - v_lo) * cv          (a: walk axis, y: the other axis)
+// and the unchecked walk of cast_rays applies unchanged with strides (ca - M cv) per step and (+-cv) per y step.
+// A band takes as many rows as its parallelogram leaves room for (the wedge's width at the band's far end plus the
+// drift |slope - M| <= 1/2 per row).  k_wedge_sort prepares the group: end cells, direction class and a counting
+// sort by (class, length) so that lanes hold the longest rays of their class first; hits, the visit counter and
+// the odd rays (leaving the map, bad beams) are its business, as they were k_ray_bits'.
+// ---------------------------------------------------------------------------------
+constexpr int kWedgeSlopes = 4;                       // slope classes per (steepness, direction): [-1,-1/2) [-1/2,0) [0,1/2) [1/2,1]
+constexpr int kWedgeClasses = 4 * kWedgeSlopes;       // x (steep?) x (walk runs away from / towards the origin)
+constexpr int kWedgeLenBins = 64;
+constexpr int kWedgeThreads = 512;
+constexpr int kWedgeSlots = 4;                        // rays per lane and pass
+constexpr int kWedgeCells = 37888;                    // 16-bit window cells (74 KiB): two workgroups per CU
+
+struct WedgeScratch {
+    uint32_t *ends;            // [rays] end cell, x | y << 16
+    uint32_t *orgs;            // [scans] origin cell
+    unsigned short *list;      // [rays] ray numbers inside their group, sorted by (class, length descending)
+    int *offs;                 // [groups][kWedgeClasses + 1] class boundaries in the group's list
+};
+
+__device__ __forceinline__ int wedge_class(const Ray &r, int ddx, int ddy)
+{
+    // minor over major displacement in [-1, 1], as the walk sees it (after the swaps the walk ascends along its axis)
+    const int maj = r.steep ? ddy : ddx, mnr = r.steep ? ddx : ddy;
+    const int q = min(kWedgeSlopes - 1, (int)(((long)(mnr * (maj < 0 ? -1 : 1) + abs(maj)) * kWedgeSlopes) / (2L * abs(maj))));
+    return ((r.steep ? 2 : 0) + (r.flag ? 1 : 0)) * kWedgeSlopes + q;
+}
+__host__ __device__ inline int wedge_shear(int cls)      // nearest integer of the class's slopes
+{
+    const int q = cls % kWedgeSlopes;
+    return q == 0 ? -1 : (q == kWedgeSlopes - 1 ? 1 : 0);
+}
+
+template <class Src>
+__global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeScratch ws, int group_size)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                   // [group_size]
+    int *hist = reinterpret_cast<int *>(smem + win_sc_bytes(group_size));                  // [kWedgeClasses * kWedgeLenBins]
+    int *wsum = hist + kWedgeClasses * kWedgeLenBins;                                       // [16] cross-wave scan
+    unsigned short *keys = reinterpret_cast<unsigned short *>(wsum + 16);                   // [group_size * n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.y, n = src.n, scans = src.scans_per_traj();
+    const int groups_per_traj = (scans + group_size - 1) / group_size;
+    const int s0 = blockIdx.x * group_size, cnt = min(group_size, scans - s0);
+    const long group = (long)l * groups_per_traj + blockIdx.x;
+    const long ray0 = ((long)l * scans + s0) * n;                     // first ray of the group in ends[]
+    uint32_t *pass = g.pass, *hit = g.hit;                            // one shared map (the launcher guarantees it)
+    if (tid < cnt) {
+        src.scan_const(l, s0 + tid, g, sc[tid]);
+        ws.orgs[(long)l * scans + s0 + tid] = (uint32_t)(sc[tid].pcx & 0xffff) | ((uint32_t)(sc[tid].pcy & 0xffff) << 16);
+    }
+    for (int k = tid; k < kWedgeClasses * kWedgeLenBins; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int nrays = cnt * n;
+    unsigned nvis = 0;
+    int bad = 0;
+    for (int r = tid; r < nrays; r += blockDim.x) {
+        const int s = r / n, i = r - s * n;
+        int pox, poy, b2 = 0;
+        Ray ry;
+        const bool valid = src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2) && ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry);
+        const bool plain = valid && (unsigned)sc[s].pcx < (unsigned)g.xw && (unsigned)sc[s].pcy < (unsigned)g.yw &&
+                           (unsigned)pox < (unsigned)g.xw && (unsigned)poy < (unsigned)g.yw;
+        unsigned short key = 0xffffu;
+        if (plain) {                                                 // every cell in the map: the path's last cell takes the hit (mapping.py:44-45)
+            nvis += (unsigned)ry.dx + 1u;
+            atomicAdd(&hit[(size_t)pox * g.yw + poy], 1u);
+            ws.ends[ray0 + r] = (uint32_t)pox | ((uint32_t)poy << 16);
+            const int cls = wedge_class(ry, pox - sc[s].pcx, poy - sc[s].pcy);
+            key = (unsigned short)(cls * kWedgeLenBins + (kWedgeLenBins - 1 - min(ry.dx >> 4, kWedgeLenBins - 1)));   // longest first
+            atomicAdd(&hist[key], 1);
+        } else if (valid) {                                          // leaves the map: the step-by-step form with direct atomics
+            const int klast = ry.flag ? 0 : ry.dx;
+            double error = 0.0;
+            int y = ry.y0, hx = -1, hy = -1;
+            for (int k = 0; k <= ry.dx; ++k) {
+                const int x = ry.x0 + k;
+                const int lx = ry.steep ? y : x, ly = ry.steep ? x : y;
+                const bool inmap = (unsigned)lx < (unsigned)g.xw && (unsigned)ly < (unsigned)g.yw;
+                nvis += inmap ? 1u : 0u;
+                if (k == klast) { hx = lx; hy = ly; }
+                else if (inmap) atomicAdd(&pass[(size_t)lx * g.yw + ly], 1u);
+                error += ry.derr;
+                if (error >= 0.5) { y += ry.ystep; error -= 1.0; }
+            }
+            if ((unsigned)hx < (unsigned)g.xw && (unsigned)hy < (unsigned)g.yw) atomicAdd(&hit[(size_t)hx * g.yw + hy], 1u);
+        }
+        keys[r] = key;
+        bad |= b2;
+    }
+    __syncthreads();
+    // exclusive scan of the 1 024 bins (one per lane of the first 16 waves; kWedgeClasses * kWedgeLenBins == 1024)
+    {
+        const int v = tid < kWedgeClasses * kWedgeLenBins ? hist[tid] : 0;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const int t = __shfl_up(inc, off, kWave); if (lane >= off) inc += t; }
+        if (lane == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (tid < kWedgeClasses * kWedgeLenBins) {
+            hist[tid] = base + inc - v;
+            if ((tid & (kWedgeLenBins - 1)) == 0) ws.offs[group * (kWedgeClasses + 1) + tid / kWedgeLenBins] = base + inc - v;
+        }
+        if (tid == blockDim.x - 1) ws.offs[group * (kWedgeClasses + 1) + kWedgeClasses] = base + inc;
+    }
+    __syncthreads();
+    for (int r = tid; r < nrays; r += blockDim.x)
+        if (keys[r] != 0xffffu) ws.list[ray0 + atomicAdd(&hist[keys[r]], 1)] = (unsigned short)r;
+    unsigned tot = wave_sum_u32(nvis);
+    int anybad = bad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anybad |= __shfl_xor(anybad, off, kWave);
+    if (lane == 0) {
+        if (tot) atomicAdd(visit_slot(g.visits), (unsigned long long)tot);
+        if (anybad) atomicOr(g.status, anybad);
+    }
+}
+
+struct WedgeRay {
+    int x0, y;             // walk origin along the axis; current y (the other axis, in walk coordinates)
+    int k, kend;           // next walk step that passes a cell, last such step (the path's last cell - the hit - is neither)
+    int ystep;
+    double error, derr;
+};
+
+__global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedge_cast(GridDev g, WedgeScratch ws, int n, int group_size, int scans)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *box = reinterpret_cast<int *>(smem);                          // [0] a_min [1] a_max [2] v_lo [3] v_hi [4] rows of the band
+    unsigned *win = reinterpret_cast<unsigned *>(smem + 64);
+    char *guard = reinterpret_cast<char *>(win) + (size_t)kWedgeCells * 2;
+    lds_guard_fill(guard);
+    STAMP_DECL;
+    int dbg_bands = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kWedgeThreads >> 6;
+    const int cls = blockIdx.x;
+    const long group = blockIdx.y;
+    const int groups_per_traj = (scans + group_size - 1) / group_size;
+    const int l = (int)(group / groups_per_traj), s0 = (int)(group % groups_per_traj) * group_size;
+    const long ray0 = ((long)l * scans + s0) * n;
+    const int lo = ws.offs[group * (kWedgeClasses + 1) + cls], hi = ws.offs[group * (kWedgeClasses + 1) + cls + 1];
+    if (lo == hi) return;
+    const bool steep = (cls / kWedgeSlopes) >= 2;
+    const int M = wedge_shear(cls);
+    uint32_t *pass = g.pass;
+    const unsigned wbase = lds_addr(win);
+
+    for (int c0 = lo; c0 < hi; c0 += kWedgeThreads * kWedgeSlots) {     // (one pass unless a class holds more than 2 048 rays)
+        WedgeRay wr[kWedgeSlots];
+        int amin = INT_MAX, amax = INT_MIN;
+#pragma unroll
+        for (int j = 0; j < kWedgeSlots; ++j) {
+            const int pos = c0 + j * kWedgeThreads + tid;                // slot 0 holds the class's longest rays
+            WedgeRay &w = wr[j];
+            w.x0 = 0; w.y = 0; w.k = 1; w.kend = 0; w.ystep = 1; w.error = 0.0; w.derr = 0.0;
+            if (pos < hi) {
+                const int r = (int)ws.list[ray0 + pos];
+                const uint32_t e = ws.ends[ray0 + r], o = ws.orgs[(long)l * scans + s0 + r / n];
+                Ray ry;
+                (void)ray_setup((int)(o & 0xffffu), (int)(o >> 16), (int)(e & 0xffffu), (int)(e >> 16), ry);
+                w.x0 = ry.x0; w.y = ry.y0; w.ystep = ry.ystep; w.derr = ry.derr;
+                w.k = 0; w.kend = ry.dx - 1;                             // walk steps 0 .. dx - 1 pass, step dx is the hit ...
+                if (ry.flag) {                                           // ... or, for a reversed path, step 0 is the hit: start one step in
+                    w.error += w.derr;                                   // bresenham.py:51-55
+                    if (w.error >= 0.5) { w.y += w.ystep; w.error -= 1.0; }
+                    w.k = 1; w.kend = ry.dx;
+                }
+                if (w.k <= w.kend) { amin = min(amin, w.x0 + w.k); amax = max(amax, w.x0 + w.kend); }
+            }
+        }
+        if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MIN; }
+        __syncthreads();
+        amin = wave_min_i32(amin); amax = wave_max_i32(amax);
+        if (lane == 0 && amin <= amax) { atomicMin(&box[0], amin); atomicMax(&box[1], amax); }
+        __syncthreads();
+        const int a_first = box[0] & ~1, a_end = box[1];               // (even band starts: pairs of counters line up for the flush)
+        for (int a_lo = a_first; a_lo <= a_end;) {
+            // rows of this band (even): try what is left (at most 512), shrink to what the parallelogram's width allows.
+            // Along a ray the sheared coordinate v = y - M a moves one way only (each step changes it by 0 or by the
+            // class's sign), so a ray's range in the band is spanned by its values on entry and on exit; the walk stays
+            // within half a cell of its line (|error| <= 1/2), which bounds the exit value before the ray is walked.
+            int rows = (min(a_end - a_lo + 1, 512) + 1) & ~1;
+            int v_lo = 0, v_hi = -1, Hw = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (tid == 0) { box[2] = INT_MAX; box[3] = INT_MIN; }
+                __syncthreads();
+                int vl = INT_MAX, vh = INT_MIN;
+#pragma unroll
+                for (int j = 0; j < kWedgeSlots; ++j) {
+                    const WedgeRay &w = wr[j];
+                    const int a_in = w.x0 + w.k, a_out = min(w.x0 + w.kend, a_lo + rows - 1);
+                    if (w.k <= w.kend && a_in <= a_out) {
+                        const double adv = (double)(a_out - a_in) * w.derr + w.error;     // y steps up to the exit, +- 1/2
+                        const int yo_lo = w.y + (w.ystep > 0 ? (int)floor(adv - 0.5) : -(int)ceil(adv + 0.5));
+                        const int yo_hi = w.y + (w.ystep > 0 ? (int)ceil(adv + 0.5) : -(int)floor(adv - 0.5));
+                        const int vi = w.y - M * a_in, vo0 = yo_lo - M * a_out, vo1 = yo_hi - M * a_out;
+                        vl = min(vl, min(vi, vo0)); vh = max(vh, max(vi, vo1));
+                    }
+                }
+                vl = wave_min_i32(vl); vh = wave_max_i32(vh);
+                if (lane == 0 && vl <= vh) { atomicMin(&box[2], vl); atomicMax(&box[3], vh); }
+                __syncthreads();
+                v_lo = box[2]; v_hi = box[3];
+                if (v_lo > v_hi) break;                                  // no ray has a cell in these rows
+                v_lo &= ~1;                                              // (even: pairs of counters line up for the flush)
+                Hw = ((v_hi - v_lo + 1) + 1) & ~1;                       // parallelogram width, even
+                const int fit = max((kWedgeCells / Hw) & ~1, 2);         // (Hw <= 2 x 16 384 + 2: two rows always fit, see launch_wedges)
+                if (rows <= fit) break;
+                rows = fit;                                              // fewer rows: the extents can only shrink
+                if (attempt == 1) break;
+                __syncthreads();
+            }
+            if (v_lo > v_hi) { a_lo += rows; __syncthreads(); continue; }
+            // physical layout: rows of C halfwords.  Not steep: a row per walk-axis step (map x), columns along map y.
+            // Steep: a row per sheared column (map x again), columns along the walk axis (map y) - contiguous in the map either way
+            const int C = steep ? rows : Hw, P = steep ? Hw : rows;
+            const int ca = steep ? 1 : C, cv = steep ? C : 1;
+            for (int w4 = tid; w4 < (P * C) >> 3; w4 += kWedgeThreads) reinterpret_cast<uint4 *>(win)[w4] = make_uint4(0u, 0u, 0u, 0u);
+            for (int w1 = ((P * C) >> 3) * 4 + tid; w1 < (P * C) >> 1; w1 += kWedgeThreads) win[w1] = 0u;
+            __syncthreads();
+            const int dh_a = ca - M * cv;
+#pragma unroll
+            for (int j = 0; j < kWedgeSlots; ++j) {
+                WedgeRay &w = wr[j];
+                const int a_in = w.x0 + w.k;
+                int rem = (w.k <= w.kend && a_in < a_lo + rows) ? min(w.x0 + w.kend, a_lo + rows - 1) - a_in + 1 : 0;
+                if (!__any(rem > 0)) continue;
+                unsigned a2 = wbase + 2u * (unsigned)((a_in - a_lo) * ca + (w.y - M * a_in - v_lo) * cv);
+                const int da_k = 2 * dh_a, da_y = 2 * w.ystep * cv;
+                double error = w.error;
+                int y = w.y;
+                const int took = rem;
+                auto step = [&]() {
+                    lds_add_u32(a2 & ~3u, 1u << ((a2 << 3) & 31u));      // mapping.py:43
+                    error += w.derr;                                     // bresenham.py:51
+                    const bool stepy = error >= 0.5;                     // :53
+                    a2 += (unsigned)(da_k + (stepy ? da_y : 0));
+                    y += stepy ? w.ystep : 0;
+                    error -= __hiloint2double(stepy ? 0x3ff00000 : 0, 0);   // :55 (minus 1.0, or minus 0.0: exact)
+                };
+                for (;;) {
+                    const bool full = rem >= 4;
+                    if (!__any(full)) break;
+                    if (full) { step(); step(); step(); step(); rem -= 4; }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (rem > u) step();
+                w.error = error; w.y = y; w.k += took;
+            }
+            __syncthreads();
+            // flush: a wave per MAP row (map x), lanes along map y, two cells per lane as one 64-bit add where the pair is
+            // aligned.  Not steep, or steep without shear: a map row is a physical row of the window.  Steep with shear: the
+            // cells of map row x lie on a diagonal of the window (column c = map y - a_lo in physical row x - M y - v_lo),
+            // read with per-lane addresses.
+            const bool diag = steep && M != 0;
+            const int nrows = diag ? P + C - 1 : P;                      // map rows the parallelogram touches
+            const int x_first = !steep ? a_lo : (M == 0 ? v_lo : v_lo + (M > 0 ? M * a_lo : M * (a_lo + C - 1)));
+            const unsigned short *winh = reinterpret_cast<const unsigned short *>(win);
+            const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)nrows);
+            for (int pr = wave; pr < nrows; pr += nwaves) {
+                const int p = pr + rot < nrows ? pr + rot : pr + rot - nrows;
+                const int mx = x_first + p;
+                if ((unsigned)mx >= (unsigned)g.xw) continue;            // (rows beyond the rays' reach hold nothing)
+                const int my0 = steep ? a_lo : v_lo + M * mx;            // map y of column 0
+                const size_t gbase = (size_t)mx * g.yw + my0;
+                const bool pair = ((gbase & 1) == 0);
+                for (int d = lane; d < (C >> 1); d += kWave) {
+                    unsigned v;
+                    if (!diag) v = win[p * (C >> 1) + d];
+                    else {
+                        const int p0 = mx - v_lo - M * (a_lo + 2 * d), p1 = p0 - M;     // physical rows of the pair's two cells
+                        const unsigned c0 = (unsigned)p0 < (unsigned)P ? winh[p0 * C + 2 * d] : 0u;
+                        const unsigned c1 = (unsigned)p1 < (unsigned)P ? winh[p1 * C + 2 * d + 1] : 0u;
+                        v = c0 | (c1 << 16);
+                    }
+                    if (!v) continue;
+                    if (pair) atomicAdd(reinterpret_cast<unsigned long long *>(&pass[gbase + 2 * d]), (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32));
+                    else {
+                        if (v & 0xffffu) atomicAdd(&pass[gbase + 2 * d], v & 0xffffu);
+                        if (v >> 16) atomicAdd(&pass[gbase + 2 * d + 1], v >> 16);
+                    }
+                }
+            }
+            a_lo += rows;
+            ++dbg_bands;
+            __syncthreads();
+        }
+    }
+#ifdef SLAM_STAMPS
+    if (tid == 0) {
+        unsigned long long *c_ = reinterpret_cast<unsigned long long *>(g.status + 8);
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - st_first;
+        atomicAdd(c_ + 0, life); atomicAdd(c_ + 1, 1ull); atomicMax(c_ + 2, life); atomicAdd(c_ + 3, (unsigned long long)dbg_bands); atomicMax(c_ + 4, (unsigned long long)dbg_bands);
+        atomicAdd(c_ + 8 + cls % 16, life);
+    }
+#endif
+    lds_guard_check(guard, g.status);
+}
+
+size_t wedge_scratch_bytes(long rays, long scans, long groups)
+{
+    return (size_t)rays * 6 + (size_t)scans * 4 + (size_t)groups * (kWedgeClasses + 1) * 4 + 4096;
+}
+
+template <class Src>
+static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s)
+{
+    if (scans < 1) return hipSuccess;
+    int G = group > 0 ? group : 16;
+    G = std::min(G, std::max(1, 65535 / n));
+    G = std::min(G, scans);
+    const int groups_per_traj = (scans + G - 1) / G;
+    const long groups = (long)L * groups_per_traj, rays = (long)L * scans * n;
+    if (groups > 65535 || g.xw > 16384 || g.yw > 16384) return hipErrorInvalidValue;   // (a band of two rows must fit the window)
+    WedgeScratch ws;
+    char *p = static_cast<char *>(scratch);
+    ws.ends = reinterpret_cast<uint32_t *>(p); p += (size_t)rays * 4;
+    ws.orgs = reinterpret_cast<uint32_t *>(p); p += (size_t)L * scans * 4;
+    ws.offs = reinterpret_cast<int *>(p); p += (size_t)groups * (kWedgeClasses + 1) * 4;
+    ws.list = reinterpret_cast<unsigned short *>(p);
+    if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
+    const size_t lds_a = win_sc_bytes(G) + (size_t)(kWedgeClasses * kWedgeLenBins + 16) * 4 + (size_t)G * n * 2;
+    const size_t lds_b = 64 + (size_t)kWedgeCells * 2 + kLdsGuard;
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_wedge_sort<Src>), (int)lds_a);
+    if (e == hipSuccess) e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_wedge_cast), (int)lds_b);
+    if (e != hipSuccess) return e;
+    SLAM_LAUNCH((k_wedge_sort<Src>), dim3(groups_per_traj, L), dim3(1024), lds_a, s, g, src, ws, G);
+    SLAM_LAUNCH(k_wedge_cast, dim3(kWedgeClasses, (unsigned)groups), dim3(kWedgeThreads), lds_b, s, g, ws, n, G, scans);
+    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256) k_grid_finalize(const uint32_t *__restrict__ pass, const uint32_t *__restrict__ hit,

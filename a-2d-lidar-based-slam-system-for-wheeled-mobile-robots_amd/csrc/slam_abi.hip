@@ -84,7 +84,7 @@ struct slam_ctx {
     std::vector<Pending> pending;
     double ms[SLAM_K_COUNT] = {0};
     int64_t launches[SLAM_K_COUNT] = {0};
-    int grid_mode = 1;    // 0: direct global atomics, 1: LDS window
+    int grid_mode = 1;    // 0: direct global atomics, 1: automatic, 2: tiles, 3: LDS window, 4: wedges
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
     int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
@@ -450,7 +450,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
 {
     TRY(use(c));
     REQUIRE(name, "null name");
-    if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "grid_mode is 0..3"); c->grid_mode = (int)value; }
+    if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3 || value == 4, "grid_mode is 0..4"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
     else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
@@ -793,11 +793,11 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     REQUIRE(g && ox && oy && cx && cy, "null pointer");
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
     Timed t(c, SLAM_K_GRID);
-    const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || c->grid_mode == 2);
-    if ((c->grid_mode == 1 || c->grid_mode == 2) && tiles_ok) {
+    const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || c->grid_mode == 2 || c->grid_mode == 4);
+    if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         size_t need = tile_scratch_bytes((long)B * n, B);
         if (need > c->tiles.cap) TRY(arena_reserve(c, c->tiles, need));
-        HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream));
+        HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream, c->grid_mode == 4));
     } else if (c->grid_mode != 0 && !grid_of_batch) {
         HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream));
     } else {
@@ -833,15 +833,15 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
                        const double *poses, const double *centres, int L, int n_scan, int n, const int32_t *got,
                        hipStream_t st)
 {
-    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || (c->grid_mode == 2 && !got);
-    if ((c->grid_mode == 1 || c->grid_mode == 2) && tiles_ok) {
+    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && !got);
+    if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         long rays = (long)L * (n_scan - 1) * n, groups = (long)L * (n_scan - 1);
         size_t need = tile_scratch_bytes(rays, groups);
         if (need > c->tiles.cap) {
             if (c->gstream) HIPCHK(hipStreamSynchronize(c->gstream));
             TRY(arena_reserve(c, c->tiles, need));
         }
-        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st));
+        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st, c->grid_mode == 4));
         return SLAM_OK;
     }
     if (c->grid_mode != 0) {

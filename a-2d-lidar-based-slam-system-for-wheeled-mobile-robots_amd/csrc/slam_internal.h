@@ -164,9 +164,9 @@ size_t tile_scratch_bytes(long rays, long groups);
 bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj);
 hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int L, int n_scan, int n, int group,
-                                    void *scratch, hipStream_t s);
+                                    void *scratch, hipStream_t s, int wedges = 0);
 hipError_t launch_grid_update_tiles_explicit(const GridDev &g, const double *ox, const double *oy, const double *cx,
-                                             const double *cy, int B, int n, int group, void *scratch, hipStream_t s);
+                                             const double *cy, int B, int n, int group, void *scratch, hipStream_t s, int wedges = 0);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);
 hipError_t launch_grid_datamap(const GridDev &g, int gi, double *datamap, hipStream_t s);
 hipError_t launch_grid_transpose(const int8_t *pmap, int xw, int yw, int8_t *data, hipStream_t s);

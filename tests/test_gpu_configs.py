@@ -52,8 +52,8 @@ def test_config4_dense_1080_f16_2000x2000_tiles(slam, syn):
     dr64 = slam.DeviceReplay(rep.ranges, AMIN, AMAX, dtype="f64")
     dr64.run()
     assert np.max(np.abs(dr64.results()[1][0] - dev["T"])) > 1e-6
-    # window mode (3) and direct atomics (0) give the same map as the tiles
-    for mode in (3, 0):
+    # the wedges (4), the window mode (3) and direct atomics (0) give the same map as the tiles
+    for mode in (4, 3, 0):
         dr.ctx.set_option("grid_mode", mode)
         dr.run()
         r = grid.read(0, want=("pass", "hit"))

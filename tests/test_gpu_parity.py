@@ -613,12 +613,13 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     ctx.close()
 
 
-def test_tiled_ray_cast_cases(slam, syn):
-    """The recorded-walk + tile path (grid_mode 2) beyond the common case: several streams into
-    one map, a small map (tiles forced), rays longer than the 2048 recorded steps (walked
-    directly), rays leaving the map, and separate ray origins."""
+@pytest.mark.parametrize("mode", [2, 4])
+def test_tiled_ray_cast_cases(slam, syn, mode):
+    """The two paths for maps much larger than a window - recorded walks + tiles (grid_mode 2), direction wedges swept
+    in bands (grid_mode 4) - beyond the common case: several streams into one map, a small map (path forced), rays
+    longer than the 2048 recorded steps / than a band, rays leaving the map, and separate ray origins."""
     ctx = slam.Context(0)
-    ctx.set_option("grid_mode", 2)
+    ctx.set_option("grid_mode", mode)
     # (a) three streams of 12 scans into one 400x400 map
     reps = [syn.make_replay(13, 200, seed=s, stride=5) for s in (7, 8, 9)]
     ranges = np.stack([r.ranges for r in reps])
