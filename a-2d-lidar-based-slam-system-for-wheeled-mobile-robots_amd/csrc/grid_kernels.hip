@@ -2078,7 +2078,7 @@ hipError_t launch_grid_update_tiles_explicit(const GridDev &g, const double *ox,
 // sort by (class, length) so that lanes hold the longest rays of their class first; hits, the visit counter and
 // the odd rays (leaving the map, bad beams) are its business, as they were k_ray_bits'.
 // ---------------------------------------------------------------------------------
-constexpr int kWedgeSlopes = 4;                       // slope classes per (steepness, direction): [-1,-1/2) [-1/2,0) [0,1/2) [1/2,1]
+constexpr int kWedgeSlopes = 4;                       // slope classes per (steepness, direction): equal parts of [-1, 1] (8: 10 % slower)
 constexpr int kWedgeClasses = 4 * kWedgeSlopes;       // x (steep?) x (walk runs away from / towards the origin)
 constexpr int kWedgeLenBins = 64;
 constexpr int kWedgeThreads = 512;
@@ -2101,8 +2101,9 @@ __device__ __forceinline__ int wedge_class(const Ray &r, int ddx, int ddy)
 }
 __host__ __device__ inline int wedge_shear(int cls)      // nearest integer of the class's slopes
 {
-    const int q = cls % kWedgeSlopes;
-    return q == 0 ? -1 : (q == kWedgeSlopes - 1 ? 1 : 0);
+    const int q = cls % kWedgeSlopes;                     // slopes [-1 + 2 q / Q, -1 + 2 (q + 1) / Q): middle (2 q + 1 - Q) / Q
+    const int mid2 = 2 * (2 * q + 1 - kWedgeSlopes);      // twice the middle, times Q
+    return mid2 >= kWedgeSlopes ? 1 : (mid2 <= -kWedgeSlopes ? -1 : 0);
 }
 
 template <class Src>
@@ -2164,21 +2165,28 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
         bad |= b2;
     }
     __syncthreads();
-    // exclusive scan of the 1 024 bins (one per lane of the first 16 waves; kWedgeClasses * kWedgeLenBins == 1024)
+    // exclusive scan of the bins: kBinsPerThread consecutive bins per thread (1 024 threads), wave scans, then the waves' totals
     {
-        const int v = tid < kWedgeClasses * kWedgeLenBins ? hist[tid] : 0;
-        int inc = v;
+        constexpr int kBinsPerThread = kWedgeClasses * kWedgeLenBins / 1024;
+        static_assert(kBinsPerThread >= 1 && kBinsPerThread * 1024 == kWedgeClasses * kWedgeLenBins && kWedgeLenBins % kBinsPerThread == 0, "bins per thread");
+        int v[kBinsPerThread], sum = 0;
+#pragma unroll
+        for (int u = 0; u < kBinsPerThread; ++u) { v[u] = hist[tid * kBinsPerThread + u]; sum += v[u]; }
+        int inc = sum;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { const int t = __shfl_up(inc, off, kWave); if (lane >= off) inc += t; }
         if (lane == kWave - 1) wsum[wave] = inc;
         __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        if (tid < kWedgeClasses * kWedgeLenBins) {
-            hist[tid] = base + inc - v;
-            if ((tid & (kWedgeLenBins - 1)) == 0) ws.offs[group * (kWedgeClasses + 1) + tid / kWedgeLenBins] = base + inc - v;
+        int run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int u = 0; u < kBinsPerThread; ++u) {
+            const int bin = tid * kBinsPerThread + u;
+            hist[bin] = run;
+            if ((bin & (kWedgeLenBins - 1)) == 0) ws.offs[group * (kWedgeClasses + 1) + bin / kWedgeLenBins] = run;
+            run += v[u];
         }
-        if (tid == blockDim.x - 1) ws.offs[group * (kWedgeClasses + 1) + kWedgeClasses] = base + inc;
+        if (tid == blockDim.x - 1) ws.offs[group * (kWedgeClasses + 1) + kWedgeClasses] = run;
     }
     __syncthreads();
     for (int r = tid; r < nrays; r += blockDim.x)
@@ -2207,8 +2215,6 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
     unsigned *win = reinterpret_cast<unsigned *>(smem + 64);
     char *guard = reinterpret_cast<char *>(win) + (size_t)kWedgeCells * 2;
     lds_guard_fill(guard);
-    STAMP_DECL;
-    int dbg_bands = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kWedgeThreads >> 6;
     const int cls = blockIdx.x;
     const long group = blockIdx.y;
@@ -2281,13 +2287,32 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
                 if (v_lo > v_hi) break;                                  // no ray has a cell in these rows
                 v_lo &= ~1;                                              // (even: pairs of counters line up for the flush)
                 Hw = ((v_hi - v_lo + 1) + 1) & ~1;                       // parallelogram width, even
-                const int fit = max((kWedgeCells / Hw) & ~1, 2);         // (Hw <= 2 x 16 384 + 2: two rows always fit, see launch_wedges)
+                const int fit = (kWedgeCells / Hw) & ~1;
+                if (fit < 2) break;                                      // not even two rows fit: the band goes by direct atomics (below)
                 if (rows <= fit) break;
                 rows = fit;                                              // fewer rows: the extents can only shrink
                 if (attempt == 1) break;
                 __syncthreads();
             }
             if (v_lo > v_hi) { a_lo += rows; __syncthreads(); continue; }
+            if ((long)Hw * 2 > kWedgeCells) {
+                // rays of one class that lie too far apart for any window (scans of a group cast from origins all over a
+                // large map): this band's cells go straight to the counters, one atomic each - slow, exact, rare
+#pragma unroll
+                for (int j = 0; j < kWedgeSlots; ++j) {
+                    WedgeRay &w = wr[j];
+                    while (w.k <= w.kend && w.x0 + w.k < a_lo + rows) {
+                        const int a = w.x0 + w.k;
+                        atomicAdd(&pass[steep ? (size_t)w.y * g.yw + a : (size_t)a * g.yw + w.y], 1u);   // mapping.py:43
+                        w.error += w.derr;                               // bresenham.py:51-55
+                        if (w.error >= 0.5) { w.y += w.ystep; w.error -= 1.0; }
+                        ++w.k;
+                    }
+                }
+                a_lo += rows;
+                __syncthreads();
+                continue;
+            }
             // physical layout: rows of C halfwords.  Not steep: a row per walk-axis step (map x), columns along map y.
             // Steep: a row per sheared column (map x again), columns along the walk axis (map y) - contiguous in the map either way
             const int C = steep ? rows : Hw, P = steep ? Hw : rows;
@@ -2360,18 +2385,9 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
                 }
             }
             a_lo += rows;
-            ++dbg_bands;
             __syncthreads();
         }
     }
-#ifdef SLAM_STAMPS
-    if (tid == 0) {
-        unsigned long long *c_ = reinterpret_cast<unsigned long long *>(g.status + 8);
-        const unsigned long long life = __builtin_amdgcn_s_memtime() - st_first;
-        atomicAdd(c_ + 0, life); atomicAdd(c_ + 1, 1ull); atomicMax(c_ + 2, life); atomicAdd(c_ + 3, (unsigned long long)dbg_bands); atomicMax(c_ + 4, (unsigned long long)dbg_bands);
-        atomicAdd(c_ + 8 + cls % 16, life);
-    }
-#endif
     lds_guard_check(guard, g.status);
 }
 
@@ -2389,7 +2405,7 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     G = std::min(G, scans);
     const int groups_per_traj = (scans + G - 1) / G;
     const long groups = (long)L * groups_per_traj, rays = (long)L * scans * n;
-    if (groups > 65535 || g.xw > 16384 || g.yw > 16384) return hipErrorInvalidValue;   // (a band of two rows must fit the window)
+    if (groups > 65535 || g.xw > 65535 || g.yw > 65535) return hipErrorInvalidValue;   // (end cells travel as 16-bit pairs)
     WedgeScratch ws;
     char *p = static_cast<char *>(scratch);
     ws.ends = reinterpret_cast<uint32_t *>(p); p += (size_t)rays * 4;

@@ -223,6 +223,10 @@ int use(slam_ctx *c)
     return SLAM_OK;
 }
 
+// maps much larger than a window: direction wedges (grid_mode 1 automatic, 4) unless the recorded-walk tiles are asked
+// for (2) or the map's sides exceed what the wedges' packed end cells hold
+int wedges_ok(const slam_ctx *c, const slam_grid *g) { return c->grid_mode != 2 && g->d.xw <= 65535 && g->d.yw <= 65535; }
+
 // stream of the pipelined map stage
 hipStream_t gs(slam_ctx *c) { return c->pipeline ? c->gstream : c->stream; }
 
@@ -797,7 +801,7 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         size_t need = tile_scratch_bytes((long)B * n, B);
         if (need > c->tiles.cap) TRY(arena_reserve(c, c->tiles, need));
-        HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream, c->grid_mode == 4));
+        HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream, wedges_ok(c, g)));
     } else if (c->grid_mode != 0 && !grid_of_batch) {
         HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream));
     } else {
@@ -841,7 +845,7 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
             if (c->gstream) HIPCHK(hipStreamSynchronize(c->gstream));
             TRY(arena_reserve(c, c->tiles, need));
         }
-        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st, c->grid_mode == 4));
+        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st, wedges_ok(c, g)));
         return SLAM_OK;
     }
     if (c->grid_mode != 0) {

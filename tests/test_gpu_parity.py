@@ -673,6 +673,20 @@ def test_tiled_ray_cast_cases(slam, syn, mode):
     assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap)
     assert g.visits() == og.visits
     g.close()
+    # (e) scans of ONE group cast from origins 38 000 cells apart on a long narrow map: rays of one direction class that no
+    #     window can hold together (the wedges' bands fall back to direct atomics; the tiles do not care)
+    cx, cy = np.array([0.3, -0.4, 0.1]), np.array([-950.0, 955.0, 10.0])
+    ang, d = rng.uniform(-np.pi, np.pi, (3, 200)), rng.uniform(0.2, 9.0, (3, 200))
+    ox, oy = cx[:, None] + np.cos(ang) * d, cy[:, None] + np.sin(ang) * d
+    g = slam.DeviceGrid(1, 400, 40000, 20.0, 10.0, 1000.0, context=ctx)
+    g.update_host(ox, oy, cx, cy)
+    og = co.Grid(400, 40000, 20.0, 10.0, 1000.0)
+    for b in range(3):
+        og.update(ox[b], oy[b], cx[b], cy[b])
+    r = g.read(0, want=("pass", "hit"))
+    assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and g.visits() == og.visits
+    assert int(r["pass"].sum()) > 10000
+    g.close()
     ctx.close()
 
 
