@@ -283,6 +283,7 @@ struct ReplaySource {
     int grid_per_traj;     // trajectory l casts into map l (particle hypotheses, BASELINE configs[2])
     const double *centres; // nullable [L][n_scan-1][2]: ray origins that are not the pose (w12-mapping-online,
                            // W12o/slam_ekf.py:71-77,104: the centre comes from /tf, the points from xEst)
+    const double *heading_cs = nullptr;   // nullable [L][n_scan-1][2]: cos / sin of the poses' headings, where the pose kernel left them
     __device__ int scans_per_traj() const { return n_scan - 1; }
     __device__ int own_grid(int l) const { return grid_per_traj ? l : 0; }
     bool maps_are_private() const { return grid_per_traj != 0; }
@@ -290,7 +291,12 @@ struct ReplaySource {
     {
         const double *pose = poses + 3 * ((size_t)l * (n_scan - 1) + k);
         sc.px = pose[0]; sc.py = pose[1];
-        sc.c = cos(pose[2]); sc.s = sin(pose[2]);
+        if (heading_cs) {
+            const double *cs = heading_cs + 2 * ((size_t)l * (n_scan - 1) + k);
+            sc.c = cs[0]; sc.s = cs[1];
+        } else {
+            sc.c = cos(pose[2]); sc.s = sin(pose[2]);
+        }
         sc.cbad = 0;
         double ox = sc.px, oy = sc.py;
         if (centres) {
@@ -393,7 +399,7 @@ template <bool COVERS, class Src>
 __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, const ScanConst *sc, int l, int s0, int n,
                                               int nrays, int *next_ray, const unsigned short *order, unsigned *win, int wx0,
                                               int wy0, int W, int H, int Hp2, uint32_t *__restrict__ pass,
-                                              uint32_t *__restrict__ hit, int first_bad)
+                                              uint32_t *__restrict__ hit, const int *first_bad)
 {
     unsigned nvis = 0;
     const int lane = threadIdx.x & 63;
@@ -406,7 +412,7 @@ __device__ __forceinline__ unsigned cast_rays(const GridDev &g, const Src &src, 
         const int r = order ? (int)order[base + lane] : base + lane;   // longest rays first when sorted
         int s = r / n, i = r - s * n, pox, poy, b2 = 0;
         Ray ry;
-        if (i >= first_bad) continue;                                // (single scan) beams from the first bad one on are not cast
+        if (i >= first_bad[s]) continue;                             // beams from the scan's first bad one on are not cast
         if (!src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) continue;
         if (!ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry)) continue;
         const int klast = ry.flag ? 0 : ry.dx;                       // walk step of the path's LAST cell
@@ -527,7 +533,7 @@ __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src 
     return nvis;
 }
 
-constexpr int kWinBoxInts = 48;        // bbox[4], window[4], flags; from [16]: the two direction halves (see k_grid_update_win)
+constexpr int kWinBoxInts = 48 + 64;   // bbox[4], window[4], flags; from [16]: the two direction halves; from [48]: every scan's first bad beam (k_grid_update_win)
 __host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)group * sizeof(ScanConst) + 15) & ~(size_t)15; }
 __host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
 __host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap, int win_cells)
@@ -575,10 +581,11 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // rows of an even number of cells: two neighbouring counters are one aligned 8-byte word, and the two
     // 16-bit counts of a window dword are flushed by ONE 64-bit atomic (see the flush)
     const bool pair64 = (g.yw & 1) == 0 && (((size_t)gi * g.xw * g.yw) & 1) == 0;
-    if (tid < cnt) src.scan_const(l, s0 + tid, g, sc[tid]);
+    int *fb = box + 48;                                              // [cnt] first beam of a scan that Python's int() would raise on
+    if (tid < cnt) { src.scan_const(l, s0 + tid, g, sc[tid]); fb[tid] = INT_MAX; }
     unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
     if (tid == 0) {
-        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull; box[15] = INT_MAX;
+        box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull;
         box[16] = box[17] = box[20] = box[21] = INT_MAX; box[18] = box[19] = box[22] = box[23] = INT_MIN;
         box[34] = 1; box[35] = 0;
     }
@@ -612,11 +619,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 hb[h][2] = side == h ? max(hb[h][2], rx1) : hb[h][2]; hb[h][3] = side == h ? max(hb[h][3], ry1) : hb[h][3];
             }
         }
-        // a single scan stops at its first beam that Python's int() would raise on (mapping.py:29-36:
-        // the beams before it have been applied when the exception leaves update(), and the error is
-        // that beam's); a group of scans reports any bad beam and casts all the others
-        if (cnt == 1) { if (b2) atomicMin(&box[15], i); }
-        else bad |= b2;
+        // a scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before
+        // it have been applied when the exception leaves update(), and the error is that beam's)
+        if (b2) atomicMin(&fb[s], i);
         if (sorted) {                                                // bin by (half,) length, longest first
             int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1) + (halves_ok ? side * kSortBins : 0);
             bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
@@ -637,12 +642,12 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         }
     }
     __syncthreads();
+    if (tid < cnt && fb[tid] != INT_MAX) {                           // the first bad beam's own error (NaN or overflow)
+        int pox, poy, b2 = 0;
+        (void)src.ray(l, s0 + tid, fb[tid], sc[tid], g, pox, poy, b2);
+        atomicOr(g.status, b2);
+    }
     if (tid == 0) {
-        if (box[15] != INT_MAX) {                                    // the first bad beam's own error (NaN or overflow)
-            int pox, poy, b2 = 0;
-            (void)src.ray(l, s0, box[15], sc[0], g, pox, poy, b2);
-            atomicOr(g.status, b2);
-        }
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         int W = 0, H = 0, covers = 1;
         int fastwin = 0, strip_w = 0;                                // strips of the single-scan owner form
@@ -746,7 +751,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         __syncthreads();
         STAMP(2);                                   // sort + zero
         // pass 2: walk the rays (the reference's float-error Bresenham, bresenham.py:45-55)
-        const int first_bad = box[15];
+        const int *first_bad = fb;
         if (covers) nvis += cast_rays<true>(g, src, sc, l, s0, n, seg1 - seg0, &box[9], ord ? ord + seg0 : nullptr, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
         else        nvis += cast_rays<false>(g, src, sc, l, s0, n, seg1 - seg0, &box[9], ord ? ord + seg0 : nullptr, win, wx0, wy0, W, H, Hp2, pass, hit, first_bad);
         __syncthreads();
@@ -808,7 +813,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         if (tid == 0) box[9] = 0;
         __syncthreads();
         STAMP(2);                                   // (sort +) zero
-        nvis += cast_rays_strip(g, src, sc[0], l, s0, nrays, &box[9], ord, win, sx0, wy0, SW, H, Hp2, hit, box[15]);
+        nvis += cast_rays_strip(g, src, sc[0], l, s0, nrays, &box[9], ord, win, sx0, wy0, SW, H, Hp2, hit, fb[0]);
         __syncthreads();
         STAMP(3);                                   // walk
         for (int q0 = tid; q0 < total; q0 += kBatch * blockDim.x) {
@@ -1676,7 +1681,7 @@ hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const doub
 
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                          const double *poses, int L, int n_scan, int n, const int32_t *got, int group,
-                                         hipStream_t s, int shared_scans, int grid_per_traj)
+                                         hipStream_t s, int shared_scans, int grid_per_traj, const double *heading_cs)
 {
     if (n_scan < 2) return hipSuccess;
     int G = pick_group(group, (long)L * (n_scan - 1), n_scan - 1, n);
@@ -1684,7 +1689,7 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
         if (shared_scans || grid_per_traj) return hipErrorInvalidValue;   // n too large for the window kernel
         return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
     }
-    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj, nullptr};
+    ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj, nullptr, heading_cs};
     return launch_win(g, src, L, n_scan - 1, n, G, got, s);
 }
 

@@ -1163,7 +1163,8 @@ __global__ void __launch_bounds__(kComposeThreads) k_pose_compose(const double *
 // M = T.[prior; 0 0 1] when a prior was applied to the source before the solve (the solve's T
 // maps the PERTURBED source, so the motion of the original scan is the product).
 __global__ void __launch_bounds__(256) k_pose_step(const double *__restrict__ T, const double *__restrict__ pose0,
-                                                   const double *__restrict__ prior, int L, double *__restrict__ poses)
+                                                   const double *__restrict__ prior, int L, double *__restrict__ poses,
+                                                   double *__restrict__ heading_cs)
 {
     int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
@@ -1181,15 +1182,19 @@ __global__ void __launch_bounds__(256) k_pose_step(const double *__restrict__ T,
     double c = cos(th), s = sin(th);
     poses[3 * l] = (x + c * m02) - s * m12;                          // :188
     poses[3 * l + 1] = (y + s * m02) + c * m12;                      // :189
-    poses[3 * l + 2] = th + dyaw;                                    // :190
+    const double th1 = th + dyaw;
+    poses[3 * l + 2] = th1;                                          // :190
+    // cos / sin of the NEW heading for the ray cast that follows (u2T, slam_ekf.py:130-137): one evaluation here
+    // instead of one per lane of the map's workgroup there; same functions, same argument bits, same results
+    if (heading_cs) { heading_cs[2 * l] = cos(th1); heading_cs[2 * l + 1] = sin(th1); }
 }
 
 hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
-                               const double *prior)
+                               const double *prior, double *heading_cs)
 {
     if (prior || (n == 1 && L > 64)) {
         if (n != 1) return hipErrorInvalidValue;
-        SLAM_LAUNCH(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses);
+        SLAM_LAUNCH(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses, heading_cs);
         return hipGetLastError();
     }
     SLAM_LAUNCH(k_pose_compose, dim3(L), dim3(kComposeThreads), 0, s, T, pose0, n, poses);

@@ -111,6 +111,7 @@ struct slam_grid {
     double *datamap_one = nullptr;
     int8_t *pmap_live = nullptr;   // [G][xw][yw], slam_grid_live_pmap
     bool live_dirty = false;       // pmap_live is behind the counters
+    bool pristine = true;          // nothing has been cast since creation / the last reset: every cell is 50
 };
 
 namespace slam {
@@ -781,6 +782,7 @@ int slam_grid_reset(slam_ctx *c, slam_grid *g)
         c->mgrid = false;
     }
     HIPCHK(hipMemsetAsync(g->d.pass, 0, g->state_bytes, gs(c)));
+    g->pristine = true;
     if (g->pmap_live) {
         HIPCHK(hipMemsetAsync(g->pmap_live, 50, (size_t)g->d.G * g->d.xw * g->d.yw, gs(c)));
         g->live_dirty = false;
@@ -796,6 +798,7 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     TRY(grid_on_main(c));
     REQUIRE(g && ox && oy && cx && cy, "null pointer");
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
+    g->pristine = false;
     Timed t(c, SLAM_K_GRID);
     const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || c->grid_mode == 2 || c->grid_mode == 4);
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
@@ -837,6 +840,7 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
                        const double *poses, const double *centres, int L, int n_scan, int n, const int32_t *got,
                        hipStream_t st)
 {
+    g->pristine = false;
     const bool tiles_ok = tiles_apply(g->d, n, got, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && !got);
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         long rays = (long)L * (n_scan - 1) * n, groups = (long)L * (n_scan - 1);
@@ -920,8 +924,13 @@ int slam_grid_live_pmap(slam_ctx *c, slam_grid *g, int8_t **pmap_dev_out)
         } else {
             HIPCHK(hipMemsetAsync(g->d.redo, 0, ((size_t)g->d.G + 2) * sizeof(int32_t), c->stream));
         }
-        g->live_dirty = true;
-        TRY(refresh_live(c, g, c->stream));
+        if (g->pristine) {                    // untouched maps: every cell is 50 (no finalize pass over G maps of zeros)
+            HIPCHK(hipMemsetAsync(g->pmap_live, 50, bytes, c->stream));
+            g->live_dirty = false;
+        } else {
+            g->live_dirty = true;
+            TRY(refresh_live(c, g, c->stream));
+        }
     }
     *pmap_dev_out = g->pmap_live;
     return SLAM_OK;
@@ -976,6 +985,7 @@ int slam_grid_counters_dev(slam_ctx *c, slam_grid *g, uint32_t **pass_dev, uint3
     REQUIRE(g && pass_dev && hit_dev, "null pointer");
     TRY(grid_on_main(c));                 // later work on the context's stream sees every update so far
     if (g->pmap_live) g->live_dirty = true;   // the caller may change the counters behind the library's back
+    g->pristine = false;
     *pass_dev = g->d.pass;
     *hit_dev = g->d.hit;
     return SLAM_OK;
@@ -1209,14 +1219,20 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }
+    double *heading_cs = nullptr;               // cos / sin of the new headings: written by the pose step, read by the ray cast
+    if (grid) {
+        TRY(arena_reserve(c, c->scratch, align_up((size_t)P * 16) + 1024));
+        heading_cs = carve<double>(c->scratch, (size_t)P * 2);
+    }
     {
         Timed t(c, SLAM_K_COMPOSE);
-        HIPCHK(launch_pose_compose(T_out, pose_prev, P, 1, poses_out, c->stream, prior));
+        HIPCHK(launch_pose_compose(T_out, pose_prev, P, 1, poses_out, c->stream, prior, heading_cs));
     }
     if (grid) {
+        grid->pristine = false;
         Timed t(c, SLAM_K_GRID);
         HIPCHK(launch_grid_update_replay_win(grid->d, ranges2, cos_t, sin_t, poses_out, P, 2, n, nullptr, 1, c->stream,
-                                             /*shared_scans=*/1, /*grid_per_traj=*/1));
+                                             /*shared_scans=*/1, /*grid_per_traj=*/1, heading_cs));
     }
     return SLAM_OK;
 }

@@ -104,8 +104,9 @@ hipError_t launch_kabsch(const double *src, const double *tar, int B, int n, dou
 hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const double *sin_t, long total,
                                  int n, int clip_inf, int dtype, void *pts, hipStream_t s);
 // prior: nullable [L][6] (n must be 1): the step composed is T.[prior; 0 0 1] (particle hypotheses).
+// heading_cs: nullable [L][2] (n must be 1): cos / sin of the new headings, for the ray cast that follows.
 hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
-                               const double *prior = nullptr);
+                               const double *prior = nullptr, double *heading_cs = nullptr);
 
 // ---- grid --------------------------------------------------------------------------
 constexpr int kMaxHitLevels = 8;
@@ -156,7 +157,7 @@ hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const doub
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t,
                                          const double *sin_t, const double *poses, int L, int n_scan, int n,
                                          const int32_t *grid_of_traj, int group, hipStream_t s, int shared_scans = 0,
-                                         int grid_per_traj = 0);
+                                         int grid_per_traj = 0, const double *heading_cs = nullptr);
 hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int S, int n, int group, hipStream_t s);
 // Tiled path for maps much larger than an LDS window (single shared map, ReplaySource only).

@@ -107,3 +107,30 @@ def test_map_state_after_a_raising_beam_equals_the_references(env, xw, live, bad
     assert np.array_equal(got["pass"], og.pass_cnt) and np.array_equal(got["hit"], og.hit_cnt)
     assert np.array_equal(got["pmap"], og.pmap) and g.visits() == og.visits
     g.close()
+
+
+def test_batched_update_stops_each_scan_at_its_first_raising_beam(env):
+    """Several scans in ONE call (the LDS-window kernel): every scan is cast up to its own first beam that int()
+    would raise on, as the reference's loop over that scan would have (mapping.py:29-36); the call reports that
+    beam's error.  (The reference's caller would not even start the scans after the offending one: those are still
+    applied here - INTEGRATION.md section 5.)"""
+    from oracle import c_oracle as co
+    slam, A, L, ctx = env
+    rng = np.random.default_rng(12)
+    B, n = 5, 120
+    ang = np.linspace(-3.1, 3.1, n)
+    r = rng.uniform(2.0, 8.0, size=(B, n))
+    cx, cy = rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)
+    ox, oy = cx[:, None] + r * np.cos(ang), cy[:, None] + r * np.sin(ang)
+    oy[1, 40] = np.nan
+    oy[1, 77] = np.inf                                           # never reached
+    ox[3, 3] = np.nan
+    g = slam.DeviceGrid(1, 400, 400, 20.0, 10.0, 10.0, context=ctx)
+    with pytest.raises(ValueError):
+        g.update_host(ox, oy, cx, cy)
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    for b, stop in ((0, n), (1, 40), (2, n), (3, 3), (4, n)):
+        og.update(ox[b, :stop], oy[b, :stop], cx[b], cy[b])
+    got = g.read(0, want=("pass", "hit"))
+    assert np.array_equal(got["pass"], og.pass_cnt) and np.array_equal(got["hit"], og.hit_cnt) and g.visits() == og.visits
+    g.close()

@@ -212,9 +212,10 @@ def test_icp_ragged_golden(slam, g3):
     assert icp.last_iters == int(g3["rag_iters"]) and np.max(np.abs(T - g3["rag_T"])) < FTOL
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (63, 64), (65, 129), (1080, 1080), (1500, 900), (2500, 700), (5000, 64)])
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (63, 64), (65, 129), (1080, 1080), (1500, 900), (2500, 700), (5000, 64), (300, 4545), (700, 8192), (8192, 8192)])
 def test_icp_batch_sizes_vs_oracle(slam, n, m):
-    """Edge sizes incl. more than one query per lane (n > 1024) and tiny clouds."""
+    """Edge sizes incl. more than one query per lane (n > 1024), tiny clouds and targets up to the documented maximum
+    of 8 192 points (the kernel's LDS then holds the padded copy of the target alone: ADVICE r2)."""
     rng = np.random.default_rng(n * 7 + m)
     B = 3
     tar = rng.normal(0, 3, size=(B, 2, m))
@@ -229,6 +230,20 @@ def test_icp_batch_sizes_vs_oracle(slam, n, m):
     oT, oit, oerr = co.icp_batch(tar, src, 12, 1e-4)
     assert np.array_equal(it, oit)
     assert np.max(np.abs(T - oT)) < FTOL and np.max(np.abs(err - oerr)) < FTOL
+
+
+@pytest.mark.parametrize("beams", [4544, 4545, 8192])
+def test_replay_largest_scans_vs_oracle(slam, syn, beams):
+    """Scans of up to 8 192 beams through the fused replay: up to 4 544 beams the scan matcher keeps a second, unpadded
+    copy of the target in LDS for its beam-window search, beyond that both copies no longer fit and it goes by the box
+    search alone - same answers either way (iteration counts exact, poses to 1e-9)."""
+    rep = syn.make_replay(3, beams, seed=21, stride=5)
+    ctx = slam.Context(0)
+    poses, T, it = slam.replay_host(rep.ranges, AMIN, AMAX, context=ctx)
+    oposes, oT, oit, _ = co.replay(rep.ranges, AMIN, AMAX, None, threads=8)
+    assert np.array_equal(it, oit)
+    assert np.max(np.abs(poses - oposes)) < FTOL and np.max(np.abs(T - oT.reshape(T.shape))) < FTOL
+    ctx.close()
 
 
 def test_icp_max_iter_zero_and_tol_zero(slam, syn):
