@@ -1350,9 +1350,10 @@ constexpr int kOwn8Bins = 128;
 constexpr int kOwn8BoxInts = 16;
 constexpr int kOwn8MaxLen = 2048;
 constexpr int kOwn8Threads = 384;       // >= kOwn8Bins, a multiple of 64: six waves, one ray per lane up to 384 beams
-constexpr int kOwn8Batch = 8;           // window rows a wave keeps in flight in the sweep (4 ... 8 measured equal)
-// LDS of a workgroup: 42 allocation granules of 1 280 bytes, so that three workgroups fit a CU's 160 KiB
-constexpr int kOwn8LdsBytes = 53760;
+constexpr int kOwn8Batch = 8;           // window rows a wave keeps in flight in the sweep (4: 15 % slower, 12: 10 % slower; 512 threads: equal)
+// LDS of a workgroup: half a CU's 160 KiB.  (Three workgroups per CU with 52.5 KiB each - the benchmark scan's box just fit -
+// were measured no faster: the kernel goes at the pace of the memory system, not of the workgroups in flight.)
+constexpr int kOwn8LdsBytes = 81920;
 // cache policy of the sweep's counter and pmap traffic (buffer aux bits: 1 sc0, 2 nt, 16 sc1): every byte is read and
 // written once per launch, and non-temporal loads AND stores run the in-place read-modify-write 24 % faster than the
 // default policy (tools/ubench_rmw.hip: 4.75 against 3.83 TB/s on this access pattern; nt on the stores alone: no gain)
@@ -1453,7 +1454,10 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     const int nv = __shfl(inc, kWave - 1, kWave);                    // non-empty rays
     if (nv == 0) return;                                             // nothing to cast (mapping.py:38-39: empty paths)
     const int x0 = min(box[0], c0.pcx), y0 = min(box[1], c0.pcy), x1 = max(box[2], c0.pcx), y1 = max(box[3], c0.pcy);
-    const int y4 = y0 & ~3, Hs = ((y1 | 3) + 1) - y4, W = x1 - x0 + 1;   // window rows of whole quads (4 cells = 16 counter bytes)
+    // window rows of whole 64-byte pieces of the counter rows (16 cells = 4 quads = 4 lanes of the sweep): a piece
+    // the scan touched is read and written back whole - runs that start or end inside a piece cost the memory
+    // system 11 % of its rate for this traffic (tools/ubench_rmw.hip: 4.29 against 4.84 TB/s)
+    const int y4 = y0 & ~15, Hs = ((y1 | 15) + 1) - y4, W = x1 - x0 + 1;
     if ((long)W * Hs > (long)win_bytes) { give_up(); return; }
     {
         const int excl = inc - (h0 + h1);
@@ -1555,7 +1559,9 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
                 const int rc = min(r, W - 1);
                 const uint32_t rowoff = (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
                 dd[u] = (incol && r < W) ? win[rc * qrow + c] : 0u;
-                const bool live = dd[u] != 0u || (r == org_r && org_lane);
+                // the four lanes of a piece decide together (rows start on a piece, 64 lanes are 16 pieces)
+                const unsigned long long m = __ballot(dd[u] != 0u || (r == org_r && org_lane));
+                const bool live = ((m >> (lane & 60)) & 0xFull) != 0ull && incol;
                 vo[u] = live ? (unsigned)lane << 4 : kSkip;         // byte offset of the lane's quad in the counter row
                 p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff << 2, kOwn8Aux);
                 om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vo[u] >> 2, rowoff, kOwn8Aux);

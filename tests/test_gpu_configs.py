@@ -383,10 +383,10 @@ def test_single_scan_byte_window_kernel_cases(slam, case):
         cells = _ring(150, 230, 30, 370, 3)                        # 81 x 341 cells: rows of 86 quads
     elif case == "box_at_capacity":
         org = (200, 200)
-        cells = _ring(88, 322, 95, 310, 4)                         # 235 x 216 = 50 760 window bytes <= 51 584
+        cells = _ring(50, 359, 100, 340, 5)                        # 310 x 256 (rows of whole 16-cell pieces, 96 .. 351) = 79 360 window bytes <= 79 808
     elif case == "box_over_capacity":
         org = (200, 200)
-        cells = _ring(80, 330, 90, 310, 4)                         # 251 x 224: beyond the window -> general kernel
+        cells = _ring(30, 370, 60, 345, 6)                         # 341 x 304: beyond the window -> general kernel
     elif case == "leaves_map":
         cells = _ring(150, 250, 150, 250, 5) + [(450, 200), (200, -30), (-5, -5)]
     elif case == "origin_in_corner":

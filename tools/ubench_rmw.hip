@@ -120,19 +120,24 @@ int main(int argc, char **argv)
     if (hipMalloc(&pass, cells * 4) != hipSuccess || hipMalloc(&hit, cells * 4) != hipSuccess || hipMalloc(&pm, cells) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMalloc(&sink, 64);
     hipMemset(pass, 0, cells * 4); hipMemset(hit, 0, cells * 4); hipMemset(pm, 50, cells);
+    // streaming references (whole 6.4 GB buffers)
+    stream<2>("stream: read", pass, hit, cells * 4, sink);
+    stream<3>("stream: write", pass, hit, cells * 4, sink);
+    stream<1>("stream: copy pass -> hit", pass, hit, cells * 4, sink);
+    stream<0>("stream: in-place RMW", pass, hit, cells * 4, sink);
+    // the sweep's pattern: rows of 52 quads starting on a 64-byte piece (y0 = 80) or 53 quads starting mid-piece (y0 = 92)
+    run<1, 4, 0, 0, 0>("read only", pass, hit, pm, P, 384, P, sink, 80, 52);
+    run<2, 4, 0, 0, 0>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
+    run<2, 4, 0, 0, 2>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
     run<0, 4, 0, 0, 0>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
     run<0, 4, 0, 0, 2>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
     run<0, 4, 0, 2, 2>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<0, 4, 0, 0, 16>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<0, 4, 0, 0, 17>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
     run<0, 4, 0, 17, 17>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<0, 4, 0, 2, 17>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<0, 4, 0, 1, 1>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<0, 4, 0, 3, 3>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<2, 4, 0, 0, 0>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<2, 4, 0, 0, 2>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<2, 4, 0, 0, 16>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<2, 4, 0, 0, 17>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
-    run<2, 4, 0, 0, 3>("write only", pass, hit, pm, P, 384, P, sink, 80, 52);
+    run<0, 4, 0, 0, 0>("RMW in place", pass, hit, pm, P, 384, P, sink, 92, 53);
+    run<0, 4, 0, 2, 2>("RMW in place", pass, hit, pm, P, 384, P, sink, 92, 53);
+    run<0, 8, 0, 2, 2>("RMW in place", pass, hit, pm, P, 384, P, sink, 80, 52);
+    run<0, 4, 0, 2, 2>("RMW in place", pass, hit, pm, P, 768, 512, sink, 80, 52);
+    run<3, 4, 0, 2, 2>("RMW + pmap read", pass, hit, pm, P, 384, P, sink, 80, 52);
+    run<4, 4, 0, 2, 2>("RMW + pmap read + 360 atomics", pass, hit, pm, P, 384, P, sink, 80, 52);
     return 0;
 }
