@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--points", default=None, choices=["f64", "f32", "f16"],
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
-    ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window; tiles on maps much larger than a window), 0: direct global atomics, 2: tiles, 3: window")
+    ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window; direction wedges on maps much larger than a window), 0: direct global atomics, 2: recorded walks + tiles, 3: window, 4: wedges")
     ap.add_argument("--grid-group", type=int, default=-1,
                     help="scans per ray-cast workgroup (0: the library's choice; default: 12 when replays overlap, else 0)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
@@ -117,7 +117,9 @@ def parse():
     if args.steps is None:
         args.steps = 48 if args.config == "replay" else 12     # (multiples of the lane counts 4 / 2 / 3: no lane runs a step more than another)
     if args.warmup is None:
-        args.warmup = 5 if args.config == "replay" else 2
+        # at least one untimed step per lane: a lane's first step allocates its workspaces (hundreds of MB for the dense
+        # configuration's ray records) and loads its kernels
+        args.warmup = 5 if args.config == "replay" else max(2, args.lanes)
     if args.grid_group < 0:
         args.grid_group = 0       # the library's choice (8 scans per ray-cast workgroup for a 1 000-scan replay; with the
                                   # direction halves that beats the 12 which round 1 used when replays overlap: 8.5 vs 8.1 M)
@@ -269,12 +271,12 @@ class ReplayWorkload:
         self.done = 0
         self.L = slam._abi.lib()
         self.units_per_step = self.lanes[0].dr.scans_per_run
-        if self.tiled():      # the tiled ray cast is two kernels timed as one family (recorded walks, then tiles)
-            self.family_kernels = dict(self.family_kernels, grid="k_ray_bits+k_tile_cast")
+        if self.tiled():      # maps much larger than a window: two kernels timed as one family (wedges; recorded walks + tiles with --grid-mode 2)
+            self.family_kernels = dict(self.family_kernels, grid="k_ray_bits+k_tile_cast" if args.grid_mode == 2 else "k_wedge_sort+k_wedge_cast")
 
     def tiled(self):
         a = self.args
-        return a.grid_mode == 2 or (a.grid_mode == 1 and a.grid * a.grid > 8 * 36864)
+        return a.grid_mode in (2, 4) or (a.grid_mode == 1 and a.grid * a.grid > 8 * 36864)
 
     def contexts(self):
         return [ln.dr.ctx for ln in self.lanes]
@@ -456,7 +458,7 @@ def config_args(base, name):
     for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
         setattr(a, k, cfg[k])
     a.scans = cfg["scans"]
-    a.steps, a.warmup = (48, 5) if name == "replay" else (12, 2)
+    a.steps, a.warmup = (48, 5) if name == "replay" else (12, max(2, cfg["lanes"]))   # every lane warms up before the timed region
     a.grid_group = 0
     a.icp_qpt = None
     return a
