@@ -223,9 +223,10 @@ def load_pmc(config, kernel):
         out = {"source": parts[0].get("source")}
         for key in ("hbm_bytes_per_launch", "valu_insts_per_launch", "lds_insts_per_launch"):
             out[key] = sum(p.get(key) or 0.0 for p in parts)
-        for key in ("valu_busy_frac", "issue_mix", "valu_insts_per_launch_qpt3"):      # of the family's main kernel
-            if parts[0].get(key) is not None:
-                out[key] = parts[0][key]
+        main = max(parts, key=lambda p: p.get("valu_insts_per_launch") or 0.0)          # the family's main kernel
+        for key in ("valu_busy_frac", "issue_mix", "valu_insts_per_launch_qpt3"):
+            if main.get(key) is not None:
+                out[key] = main[key]
     else:
         out = dict(d.get(kernel, {}))
     if out and stale:

@@ -74,8 +74,10 @@ int slam_synchronize(slam_ctx *ctx);
 int slam_check_status(slam_ctx *ctx);
 /* Tuning knobs (results never depend on them).
  * "grid_mode": 1 = automatic (default): ray casting through an LDS window per group of scans,
- *   or - for one shared map much larger than a window - walks recorded once and cast tile by
- *   tile; 0 = direct global atomics; 2 = tiles wherever they apply; 3 = always the window.
+ *   or - for one shared map much larger than a window - rays dealt by direction and swept in
+ *   bands through a sheared window (wedges); 0 = direct global atomics; 2 = walks recorded once
+ *   and cast tile by tile, wherever that applies; 3 = always the window; 4 = wedges wherever
+ *   they apply.
  * "grid_group": scans per workgroup / per tile group, 0 = automatic.
  * "icp_qpt": queries per lane of batched scan matching, 1..3; 0 = by batch size (two for
  *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
@@ -114,7 +116,12 @@ int slam_nn_dev(slam_ctx *ctx, const void *src, const void *tar, int B, int n_sr
                 double *dist, int32_t *idx);
 
 /* Replaces ICP.getTransform(src, tar) (W12m/icp.py:149-179): rigid 2-D fit of paired
- * rows; src, tar [B][2][n] float64; T_out [B][9]. */
+ * rows; src, tar [B][2][n] float64; T_out [B][9].
+ * DOCUMENTED DEVIATION: when every row of src or of tar is ONE point (bitwise), W = BB^T.AA is
+ * mathematically zero and every rotation is optimal; the reference's SVD then sees the rounding
+ * noise of np.mean and returns an arbitrary rotation (tests/golden/g8_collapsed.npz holds eight,
+ * 16 .. 170 degrees).  This function returns the canonical R = I, t = centroid_tar - centroid_src;
+ * both answers move the source centroid onto the matched point. */
 int slam_kabsch2d(slam_ctx *ctx, const double *src, const double *tar, int B, int n, double *T_out);
 int slam_kabsch2d_dev(slam_ctx *ctx, const double *src, const double *tar, int B, int n, double *T_out);
 
@@ -124,7 +131,9 @@ int slam_kabsch2d_dev(slam_ctx *ctx, const double *src, const double *tar, int B
  * prior: NULL, or [B][6] row-major 2x3 matrices applied to the source points first
  * (x' = p0*x + p1*y + p2; y' = p3*x + p4*y + p5): the perturbed-prior particle batch of
  * BASELINE.json configs[2]; the returned T maps the perturbed source.
- * T_out [B][9]; iters_out [B] and mean_err_out [B] may be NULL. */
+ * T_out [B][9]; iters_out [B] and mean_err_out [B] may be NULL.
+ * n_tar, n_src <= 8192.  The rigid fit of every iteration follows slam_kabsch2d, including its
+ * canonical R = I for collapsed correspondences (every source point matched to one target). */
 int slam_icp_batch(slam_ctx *ctx, const void *tar, const void *src, int B, int n_tar, int n_src,
                    int dtype, int tar_shared, int src_shared, const double *prior, int max_iter,
                    double tol, double *T_out, int32_t *iters_out, double *mean_err_out);
