@@ -553,7 +553,7 @@ inline int win_cells_for(int group, int sort_cap)
 
 template <class Src>
 __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, int group_size, const int32_t *__restrict__ got,
-                                                          int exclusive, int sort_cap, int win_cells)
+                                                          int exclusive, int sort_cap, int win_cells, int split)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS is carved for this launch's group size (win_lds_bytes): a small group leaves room for a
@@ -569,7 +569,11 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int l = blockIdx.y;
-    const int s0 = blockIdx.x * group_size;
+    // split: TWO workgroups per group of scans, one per direction half - a ray never crosses the column of its origin,
+    // so the rays running towards larger x and those running towards smaller x touch disjoint halves of the group's
+    // box and can be cast by different CUs: each walks its half's rays into its own window and flushes it
+    const int my_half = split ? (int)(blockIdx.x & 1u) : -1;
+    const int s0 = (int)(split ? blockIdx.x >> 1 : blockIdx.x) * group_size;
     const int cnt = min(group_size, src.scans_per_traj() - s0);
     const int gi = got ? got[l] : src.own_grid(l);
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
@@ -596,7 +600,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // When the whole box does not fit the window - a 10 m x 8 m room seen at an angle spans 250 x 250
     // cells, 1.5 windows - each half gets the window to itself, one after the other: every ray is still
     // walked once, and none of its cells takes the scattered-global-atomic path (40 % of the walk before).
-    const bool halves_ok = sorted && !exclusive;
+    const bool halves_ok = sorted && !exclusive && !split;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
     for (int k = tid; k < 2 * kSortBins; k += blockDim.x) hist[k] = 0;
     __syncthreads();
@@ -608,11 +612,15 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     for (int r = tid; r < nrays; r += blockDim.x) {
         int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0, side = 0;
         if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) {
+            side = pox >= sc[s].pcx ? 1 : 0;
+            if (split && side != my_half) {                          // the other workgroup's ray (an error of the beam is both's: b2 is 0 here)
+                bins[r] = 0xffffu;
+                continue;
+            }
             const int rx0 = min(pox, sc[s].pcx), rx1 = max(pox, sc[s].pcx), ry0 = min(poy, sc[s].pcy), ry1 = max(poy, sc[s].pcy);
             bx0 = min(bx0, rx0); bx1 = max(bx1, rx1);
             by0 = min(by0, ry0); by1 = max(by1, ry1);
             len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
-            side = pox >= sc[s].pcx ? 1 : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 hb[h][0] = side == h ? min(hb[h][0], rx0) : hb[h][0]; hb[h][1] = side == h ? min(hb[h][1], ry0) : hb[h][1];
@@ -624,8 +632,9 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         if (b2) atomicMin(&fb[s], i);
         if (sorted) {                                                // bin by (half,) length, longest first
             int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1) + (halves_ok ? side * kSortBins : 0);
+            if (split && len == 0 && my_half != 0) bin = 0xffff;     // (skipped / invalid beams: nothing to cast, half 0 keeps them)
             bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
-            atomicAdd(&hist[bin], 1);
+            if (bin != 0xffff) atomicAdd(&hist[bin], 1);
         }
     }
     bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
@@ -731,15 +740,17 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             for (int u = 0; u < 4; ++u) { hist[4 * lane + u] = run; run += h4[u]; }
         }
         __syncthreads();
-        for (int r = tid; r < nrays; r += blockDim.x) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
+        for (int r = tid; r < nrays; r += blockDim.x)
+            if (bins[r] != 0xffffu) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
         __syncthreads();
     }
+    const int nmine = split ? box[35] : nrays;                       // rays this workgroup casts (split: its half's, sorted)
     unsigned nvis = 0;
     const unsigned short *ord = sorted ? order : nullptr;
     const int strips = box[10], strip_w = box[11];
     const bool fast = strips != 0;        // single-scan owner form (the sweep at the end of the kernel)
     for (int ph = 0; ph < (fast ? 0 : phases); ++ph) {
-        int seg0 = 0, seg1 = nrays;
+        int seg0 = 0, seg1 = nmine;
         if (phases == 2) {
             const int *o = ph ? box + 24 : box + 4;
             wx0 = o[0]; wy0 = o[1]; W = o[2]; H = o[3]; covers = o[4] != 0; Hp2 = (H + 1) >> 1;
@@ -1611,7 +1622,7 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
 
 template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
-                             hipStream_t s)
+                             hipStream_t s, int split_pref = -1)
 {
     const size_t lds_max = win_lds_bytes(kWinMaxGroup, kMaxSortRays, kWinCells);
     {
@@ -1656,8 +1667,13 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
         else                    SLAM_LAUNCH((k_grid_update_owner<Src, 2>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
         return hipGetLastError();
     }
-    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
-                exclusive, sort_cap, win_cells);
+    // Two workgroups per group, one per direction half, where the rays are sorted and the map is not the workgroup's own:
+    // a launch that cannot fill the chip on its own (a 1 000-scan replay is 125 groups on 256 CUs) runs 11 % shorter
+    // that way (0.088 -> 0.078 ms); when launches of several contexts share the chip the duplicated first pass costs
+    // 4 % of the throughput, so callers that overlap replays switch it off (context option "grid_split")
+    const int split = (!exclusive && sort_cap > 0 && (split_pref > 0 || (split_pref < 0 && (long)groups * L <= 192))) ? 1 : 0;
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(split ? 2 * groups : groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
+                exclusive, sort_cap, win_cells, split);
     return hipGetLastError();
 }
 
@@ -1677,17 +1693,17 @@ static int pick_group(int group, long total_scans, int scans_per_traj, int n)
 }
 
 hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const double *oy, const double *cx, const double *cy,
-                                  int B, int n, int group, hipStream_t s)
+                                  int B, int n, int group, hipStream_t s, int split_pref)
 {
     int G = pick_group(group, B, B, n);
     if (G == 0) return launch_grid_update(g, ox, oy, cx, cy, B, n, nullptr, s);
     ExplicitSource src{ox, oy, cx, cy, B, n};
-    return launch_win(g, src, 1, B, n, G, nullptr, s);
+    return launch_win(g, src, 1, B, n, G, nullptr, s, split_pref);
 }
 
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                          const double *poses, int L, int n_scan, int n, const int32_t *got, int group,
-                                         hipStream_t s, int shared_scans, int grid_per_traj, const double *heading_cs)
+                                         hipStream_t s, int shared_scans, int grid_per_traj, const double *heading_cs, int split_pref)
 {
     if (n_scan < 2) return hipSuccess;
     int G = pick_group(group, (long)L * (n_scan - 1), n_scan - 1, n);
@@ -1696,18 +1712,18 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
         return launch_grid_update_replay(g, ranges, cos_t, sin_t, poses, L, n_scan, n, got, s);
     }
     ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, shared_scans ? 0L : (long)n_scan * n, grid_per_traj, nullptr, heading_cs};
-    return launch_win(g, src, L, n_scan - 1, n, G, got, s);
+    return launch_win(g, src, L, n_scan - 1, n, G, got, s, split_pref);
 }
 
 // S scans cast from given poses, optionally with ray origins of their own.
 hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
-                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s)
+                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s, int split_pref)
 {
     int G = pick_group(group, S, S, n);
     if (G == 0) return hipErrorInvalidValue;                          // n too large for the window kernel
     // the replay source reads scan k+1 of a stream of n_scan = S+1: shift the base by one scan
     ReplaySource src{ranges - n, cos_t, sin_t, poses, S + 1, n, 0L, 0, centres};
-    return launch_win(g, src, 1, S, n, G, nullptr, s);
+    return launch_win(g, src, 1, S, n, G, nullptr, s, split_pref);
 }
 
 // ---------------------------------------------------------------------------------

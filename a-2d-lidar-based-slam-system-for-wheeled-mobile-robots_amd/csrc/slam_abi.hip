@@ -86,6 +86,7 @@ struct slam_ctx {
     int64_t launches[SLAM_K_COUNT] = {0};
     int grid_mode = 1;    // 0: direct global atomics, 1: automatic, 2: tiles, 3: LDS window, 4: wedges
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
+    int grid_split = -1;  // window mode: two workgroups per group, one per direction half (-1: when the launch cannot fill the chip)
     int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
     // a second stream, so the map stage of one replay overlaps the scan matching of the next.
@@ -457,6 +458,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     REQUIRE(name, "null name");
     if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3 || value == 4, "grid_mode is 0..4"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
+    else if (!strcmp(name, "grid_split")) { REQUIRE(value == -1 || value == 0 || value == 1, "grid_split is -1, 0 or 1"); c->grid_split = (int)value; }
     else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
         REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
@@ -806,7 +808,7 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
         if (need > c->tiles.cap) TRY(arena_reserve(c, c->tiles, need));
         HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream, wedges_ok(c, g)));
     } else if (c->grid_mode != 0 && !grid_of_batch) {
-        HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream));
+        HIPCHK(launch_grid_update_win(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->stream, c->grid_split));
     } else {
         HIPCHK(launch_grid_update(g->d, ox, oy, cx, cy, B, n, grid_of_batch, c->stream));
     }
@@ -853,8 +855,8 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
         return SLAM_OK;
     }
     if (c->grid_mode != 0) {
-        if (centres) HIPCHK(launch_grid_update_scans(g->d, ranges + n, cos_t, sin_t, poses, centres, n_scan - 1, n, c->grid_group, st));
-        else HIPCHK(launch_grid_update_replay_win(g->d, ranges, cos_t, sin_t, poses, L, n_scan, n, got, c->grid_group, st));
+        if (centres) HIPCHK(launch_grid_update_scans(g->d, ranges + n, cos_t, sin_t, poses, centres, n_scan - 1, n, c->grid_group, st, c->grid_split));
+        else HIPCHK(launch_grid_update_replay_win(g->d, ranges, cos_t, sin_t, poses, L, n_scan, n, got, c->grid_group, st, 0, 0, nullptr, c->grid_split));
         return SLAM_OK;
     }
     REQUIRE(!centres, "grid_mode 0 has no separate ray origins");

@@ -152,14 +152,15 @@ hipError_t launch_grid_update_replay(const GridDev &g, const float *ranges, cons
                                      const int32_t *grid_of_traj, hipStream_t s);
 // LDS-window variants (group = scans per workgroup, 0 = automatic); they fall back to the
 // direct-atomic kernels when a scan has too many beams for the packed window counters.
+// split_pref: two workgroups per group of scans, one per direction half: -1 = when the launch cannot fill the chip, 0 = never, 1 = always
 hipError_t launch_grid_update_win(const GridDev &g, const double *ox, const double *oy, const double *cx,
-                                  const double *cy, int B, int n, int group, hipStream_t s);
+                                  const double *cy, int B, int n, int group, hipStream_t s, int split_pref = -1);
 hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, const double *cos_t,
                                          const double *sin_t, const double *poses, int L, int n_scan, int n,
                                          const int32_t *grid_of_traj, int group, hipStream_t s, int shared_scans = 0,
-                                         int grid_per_traj = 0, const double *heading_cs = nullptr);
+                                         int grid_per_traj = 0, const double *heading_cs = nullptr, int split_pref = -1);
 hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
-                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s);
+                                    const double *poses, const double *centres, int S, int n, int group, hipStream_t s, int split_pref = -1);
 // Tiled path for maps much larger than an LDS window (single shared map, ReplaySource only).
 size_t tile_scratch_bytes(long rays, long groups);
 bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj);

@@ -262,6 +262,9 @@ class ReplayWorkload:
             ln.dr.ctx.set_option("grid_mode", args.grid_mode)
             ln.dr.ctx.set_option("grid_group", args.grid_group)
             ln.dr.ctx.set_option("pipeline", args.pipeline)
+            # several replays share the chip: one workgroup per group of scans (least total work); a lone replay leaves
+            # the choice to the library (two, one per direction half: shortest launch)
+            ln.dr.ctx.set_option("grid_split", 0 if n_lanes > 1 else -1)
             # several replays share the chip: three queries per lane (fewest instructions); a lone
             # replay leaves the choice to the library (two: shortest launch)
             ln.dr.ctx.set_option("icp_qpt", args.icp_qpt if args.icp_qpt is not None else int(os.environ.get("SLAM_BENCH_QPT", 3 if n_lanes > 1 else 0)))

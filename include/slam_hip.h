@@ -79,6 +79,10 @@ int slam_check_status(slam_ctx *ctx);
  *   and cast tile by tile, wherever that applies; 3 = always the window; 4 = wedges wherever
  *   they apply.
  * "grid_group": scans per workgroup / per tile group, 0 = automatic.
+ * "grid_split": LDS-window ray cast with two workgroups per group of scans, one per direction
+ *   half (a ray never crosses the column of its origin): -1 = automatic (default: when the launch
+ *   cannot fill the chip on its own - shorter launch, a little more total work), 0 = never
+ *   (callers that overlap launches of several contexts), 1 = always.
  * "icp_qpt": queries per lane of batched scan matching, 1..3; 0 = by batch size (two for
  *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
  *   overlap several smaller launches set 3).
