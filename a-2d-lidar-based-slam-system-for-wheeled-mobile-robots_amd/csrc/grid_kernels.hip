@@ -1660,7 +1660,7 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
             const int own8_lds = kOwn8LdsBytes + kLdsGuard, own8_win = (int)(kOwn8LdsBytes - own8_fixed_bytes(kOwn8Threads));
             SLAM_LAUNCH((k_grid_update_owner8<Src, kOwn8Threads, kOwn8Batch>), dim3(1, L), dim3(kOwn8Threads), own8_lds, s,
                         g, src, own8_win, g.redo);
-            SLAM_LAUNCH((k_grid_update_owner_redo<Src, 1>), dim3(std::min(L, 512)), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells, g.redo);
+            SLAM_LAUNCH((k_grid_update_owner_redo<Src, 1>), dim3(std::min(L, 256)), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells, g.redo);
             return hipGetLastError();
         }
         if (n <= kOwnerThreads) SLAM_LAUNCH((k_grid_update_owner<Src, 1>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
