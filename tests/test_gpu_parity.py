@@ -606,9 +606,10 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     ctx = slam.Context(0)
     og = co.Grid(2000, 2000, 50.0, 20.0, 20.0)
     oposes, _, _, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8, mt_grid=True)
-    for mode in (0, 1, 2, 3):        # direct atomics, automatic (= tiles on a map this large), tiles, window
-        ctx.set_option("grid_mode", mode)
-        ctx.set_option("grid_group", group)
+    for mode, split in ((0, -1), (1, -1), (2, -1), (3, 0), (3, 1), (4, -1)):   # direct atomics, automatic (= wedges on a map this
+        ctx.set_option("grid_mode", mode)                                       # large), tiles, window with one / two workgroups
+        ctx.set_option("grid_group", group)                                     # per group of scans, wedges
+        ctx.set_option("grid_split", split)
         grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02, context=ctx)
         poses, _, _ = slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, context=ctx)
         r = grid.read(0, want=("pass", "hit"))
@@ -620,12 +621,34 @@ def test_grid_window_modes_are_bit_identical(slam, syn, group):
     wp = [co.world_points(p, x, y) for p, (x, y) in zip(oposes, pts)]
     ox, oy = np.stack([w[0] for w in wp]), np.stack([w[1] for w in wp])
     ctx.set_option("grid_mode", 1)
+    ctx.set_option("grid_split", -1)
     grid = slam.DeviceGrid.metric(1, 2000, 2000, 0.02, context=ctx)
     grid.update_host(ox, oy, oposes[:, 0], oposes[:, 1])
     r = grid.read(0, want=("pass", "hit"))
     assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt)
     grid.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_window_kernel_one_or_two_workgroups_per_group(slam, syn, split):
+    """The window ray cast with one workgroup per group of scans, or two - one per direction half (a ray never crosses
+    the column of its origin) - on the benchmark's map: 120 scans in groups of 1, 7 and 12 (ragged last group): same
+    counters, same visits."""
+    rep = syn.make_replay(121, 360, seed=6, stride=5)
+    og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+    _, _, _, ov = co.replay(rep.ranges, AMIN, AMAX, og, threads=8, mt_grid=True)
+    for group in (1, 7, 12):
+        ctx = slam.Context(0)
+        ctx.set_option("grid_mode", 3)
+        ctx.set_option("grid_group", group)
+        ctx.set_option("grid_split", split)
+        grid = slam.DeviceGrid.metric(1, 400, 400, 0.05, context=ctx)
+        slam.replay_host(rep.ranges, AMIN, AMAX, grid=grid, context=ctx)
+        r = grid.read(0, want=("pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and grid.visits() == ov, group
+        grid.close()
+        ctx.close()
 
 
 @pytest.mark.parametrize("mode", [2, 4])
