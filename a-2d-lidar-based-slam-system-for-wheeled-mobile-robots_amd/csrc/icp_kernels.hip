@@ -22,6 +22,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "slam_internal.h"
 #include "slam_stamps.h"
 
@@ -84,10 +86,46 @@ __device__ __forceinline__ double wave_sum_f64(double x)
     return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
 }
 
+// Sum of nwaves doubles in LDS, `stride` apart, added in ascending order to 0.0 - the cross-wave stage of the
+// reductions below.  The reads are issued together (a loop over a run-time count waits for every read before it
+// issues the next: 150 cycles a wave, twice per iteration on the critical path of a solve and eight times behind it).
+template <int NW>
+__device__ __forceinline__ double lds_column_n(const double *p, int stride)
+{
+    double x[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x[w] = p[w * stride];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += x[w];
+    return t;
+}
+__device__ __forceinline__ double lds_column(const double *p, int stride, int nwaves)
+{
+    switch (nwaves) {                      // (the workgroup shapes of the benchmark configurations first)
+    case 3: return lds_column_n<3>(p, stride);
+    case 2: return lds_column_n<2>(p, stride);
+    case 6: return lds_column_n<6>(p, stride);
+    case 9: return lds_column_n<9>(p, stride);
+    case 4: return lds_column_n<4>(p, stride);
+    case 5: return lds_column_n<5>(p, stride);
+    case 8: return lds_column_n<8>(p, stride);
+    case 16: return lds_column_n<16>(p, stride);
+    }
+    double t = 0.0;
+    int w = 0;
+    for (; w + 4 <= nwaves; w += 4) {
+        const double x0 = p[w * stride], x1 = p[(w + 1) * stride], x2 = p[(w + 2) * stride], x3 = p[(w + 3) * stride];
+        t += x0; t += x1; t += x2; t += x3;
+    }
+    for (; w < nwaves; ++w) t += p[w * stride];
+    return t;
+}
+
 // Sum NV doubles over the workgroup; every thread receives the (bitwise identical)
 // totals.  Fixed exchange pattern + fixed wave order: deterministic run to run.  `scratch`
-// ([NV][kMaxWaves]) must alternate between two buffers on consecutive calls (no trailing
-// barrier).
+// must alternate between two buffers on consecutive calls (no trailing
+// barrier).  ([NV][nwaves] doubles.)
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int nwaves, int wave, int lane)
 {
@@ -96,15 +134,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int 
     if (nwaves == 1) return;
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) scratch[k * kMaxWaves + wave] = v[k];
+        for (int k = 0; k < NV; ++k) scratch[k * nwaves + wave] = v[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += scratch[k * kMaxWaves + w];
-        v[k] = s;
-    }
+    for (int k = 0; k < NV; ++k) v[k] = lds_column(scratch + k * nwaves, 1, nwaves);
 }
 
 // Transposed wave reduction: N = 8 (or 4) values are summed over the wave's 64 lanes in 58 (33)
@@ -117,7 +151,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int 
 // xor mask and under none of the later ones.  Afterwards lane l holds the wave total of value
 // sigma1 + 2 sigma2 (+ 4 sigma3): lanes 0..3 hold values 0..3, lanes 7, 6, 5, 4 values 4..7.
 // Fixed order: deterministic, the same in every lane that holds the same value.
-struct LaneSel { bool s1, s2, s3; int idx8, idx4; };
+struct LaneSel { bool s1, s2, s3, s4; int idx8, idx4, idx16; };
 __device__ __forceinline__ LaneSel lane_sel(int lane)
 {
     LaneSel s;
@@ -126,6 +160,8 @@ __device__ __forceinline__ LaneSel lane_sel(int lane)
     s.s3 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0;
     s.idx4 = (s.s1 ? 1 : 0) + (s.s2 ? 2 : 0);
     s.idx8 = s.idx4 + (s.s3 ? 4 : 0);
+    s.s4 = ((lane >> 3) & 1) != 0;                     // flips under the row mirror (xor 15), the last exchange
+    s.idx16 = s.idx8 + (s.s4 ? 8 : 0);
     return s;
 }
 template <int CTRL>
@@ -162,17 +198,27 @@ __device__ __forceinline__ double wave_reduce4(const double (&v)[4], const LaneS
     u += dpp_xchg<0x140>(u);
     return rows_sum_f64(u);
 }
+// Nine values: one more halving step at the row mirror (selection bit b3).  Afterwards lane l holds the wave total
+// of value idx16(l): values 0..7 where wave_reduce8 leaves them, value 8 in lane 15; idx16 9..15 hold zeros.
+__device__ __forceinline__ double wave_reduce9(const double (&v)[9], const LaneSel &s)
+{
+    const double r0 = tstep<0xB1>(v[0], v[1], s.s1), r1 = tstep<0xB1>(v[2], v[3], s.s1);
+    const double r2 = tstep<0xB1>(v[4], v[5], s.s1), r3 = tstep<0xB1>(v[6], v[7], s.s1);
+    const double r4 = tstep<0xB1>(v[8], 0.0, s.s1);
+    const double t0 = tstep<0x4E>(r0, r1, s.s2), t1 = tstep<0x4E>(r2, r3, s.s2), t2 = tstep<0x4E>(r4, 0.0, s.s2);
+    const double x0 = tstep<0x141>(t0, t1, s.s3), x1 = tstep<0x141>(t2, 0.0, s.s3);
+    return rows_sum_f64(tstep<0x140>(x0, x1, s.s4));
+}
 // Workgroup total of the value this lane holds after wave_reduce8 / 4: lanes 0..7 of every wave
-// leave theirs in scratch[wave][value], and after the barrier every lane adds its value's column in
-// wave order.  `scratch` ([kMaxWaves][8]) alternates between two buffers on consecutive calls.
+// (0..15 with nine values) leave theirs in scratch[wave][value], and after the barrier every lane adds its
+// value's column in wave order.  `scratch` ([nwaves][NV]) alternates between two buffers on consecutive calls.
+template <int NV = 8>
 __device__ __forceinline__ double block_total(double mine, int idx, double *scratch, int nwaves, int wave, int lane)
 {
     if (nwaves == 1) return mine;
-    if (lane < 8) scratch[wave * 8 + idx] = mine;
+    if (lane < (NV > 8 ? 16 : 8) && idx < NV) scratch[wave * NV + idx] = mine;
     __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < nwaves; ++w) t += scratch[w * 8 + idx];
-    return t;
+    return lds_column(scratch + min(idx, NV - 1), NV, nwaves);
 }
 
 struct Rigid2 {
@@ -391,7 +437,10 @@ constexpr int kPolarMax = 32;     // widest window (beams) the polar search take
 // as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
 // lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
 constexpr int kPolarMaxLone = 96;
+constexpr int kPolarMaxFirst = 32;            // ... and in a first iteration whose wider ones are listed (nn_listed),
+constexpr int kPolarMaxListed = 48;           // where a window may be this wide after the re-guess
 constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
+constexpr bool kOnePass = true;               // iterations after the first: centroids and centred products in one reduction (k_icp)
 constexpr int kPolarTail = 4;                 // NaN points behind the beam-window search's copy of the target
 
 template <typename T> struct StoreSlack { static constexpr float ang = 2e-7f; };              // float64 points
@@ -405,7 +454,8 @@ struct PolarGeo {
 
 template <int UNROLL, bool PROBE>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
-                                         bool active, const PolarGeo &geo, double &best_d2, int &best_j, bool &big, bool &amb)
+                                         bool active, const PolarGeo &geo, int wmax, bool probe, double &best_d2,
+                                         int &best_j, bool &big, bool &amb)
 {
     seed = min(max(seed, 0), n_tar - 1);
     const float fsx = (float)sx, fsy = (float)sy;
@@ -438,7 +488,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         const float fn = (float)n_tar;
         wlo = j + (int)floorf(fmaxf(-fn, fminf(0.0f, (dlo - alpha) * geo.inv_db)));
         whi = j + (int)ceilf(fminf(fn, fmaxf(0.0f, (dhi + alpha) * geo.inv_db)));
-        return small && whi - wlo < (PROBE ? kPolarMax : kPolarMaxLone);
+        return small && whi - wlo < wmax;
     };
     auto scan = [&](int a0, int a1, Best &b) {
         // UNROLL 4: four candidates per trip, their LDS reads in flight together.  A launch that cannot fill
@@ -478,7 +528,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     // 10 000 pairs 0.425 -> 0.395 ms.  A lone 999-pair launch with two queries per lane is bound by the latency
     // of its longest solves and got SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter:
     // a workgroup waits for its slowest wave, and 65 % of the pairs still have one that needs the box search.)
-    if (PROBE && __any(active && !fits)) {
+    if (PROBE && probe && __any(active && !fits)) {
         // A guess that bounds nothing useful - before the first update source and target point of one beam
         // lie on ONE ray, and where the two scans see different surfaces there (14 % of the lanes, in 84 %
         // of the wave-queries) the bound is the range jump - is replaced by the best of the 17 beams around
@@ -510,6 +560,102 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     best_d2 = b.d2;
     best_j = b.j;
     amb = go && b.amb();
+}
+
+// ---------------------------------------------------------------------------------
+// nn_listed: the FIRST iteration's queries without a usable beam window, taken out of the lanes that own them.
+// Before the first update a query and its guess lie on one ray, and where the two scans see different
+// surfaces there the bound is the range jump: a window of dozens of beams for 9-14 % of the queries,
+// scattered over 71 % of the wave-queries - and a wave whose lane re-guesses or takes the box search waits for
+// it (a quarter of a 999-pair launch's duration).  k_icp lists such queries in LDS; here they are dealt out
+// again, one per lane, to as few waves as hold them (the others wait at the barrier and leave the SIMDs to
+// other pairs): each lane re-guesses among the beams around the first guess and searches the window of the
+// better guess (nn_polar with PROBE).  What is still left - no surface near the ray at all, 0.4 % of the
+// queries - is searched exhaustively, four queries at a time, by the rows of 16 lanes of the wave: lane r of a
+// row looks at targets r, r + 16, ... in ascending order under Best's rule, then the 16 partial results are
+// merged by (square, index): the smallest square, of equal squares the lowest index - what the reference's
+// strict '<' over ascending indices keeps.  The tie bookkeeping carries over: a merge raises the flag when its
+// winner replaces a lower-indexed candidate less than a class of equal roots above it (the event Best
+// watches for), and flags are inherited from both sides; a candidate of lower index inside the winner's
+// class always meets such a merge on its way up, whatever the order of the merges.
+// qlist[e]: in (x, y) of the query, out (square, index | flag << 31 in the low word of .y); qseed[e]: its guess.
+// ---------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_xchg_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+
+template <int CTRL>
+__device__ __forceinline__ void team_merge(double &d, int &jf)
+{
+    const double od = dpp_xchg<CTRL>(d);
+    const int ojf = dpp_xchg_i<CTRL>(jf);
+    const int j = jf & 0x7fffffff, oj = ojf & 0x7fffffff;
+    const bool owin = od < d || (od == d && oj < j);
+    const double dw = owin ? od : d, dl = owin ? d : od;
+    const int jw = owin ? oj : j, jl = owin ? j : oj;
+    const bool ev = dw < dl && jl < jw && !(dw * kTieAbove < dl);
+    d = dw;
+    jf = jw | ((jf | ojf) & (int)0x80000000) | (ev ? (int)0x80000000 : 0);
+}
+
+// one query against the whole target by the 16 lanes of a DPP row; every lane of the row returns the result
+__device__ __forceinline__ void nn_row(const double2 *__restrict__ tarP, int n_tar, double2 qp, double &bd, int &jf)
+{
+    const int r = threadIdx.x & 15;
+    bd = INFINITY;
+    int bj = 0;
+    bool f = false;
+    for (int jb = r; jb < n_tar + r; jb += 64) {                     // a lane past the last target reads the NaN point behind it
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + 16 * u;
+            const double2 t = tarP[min(j, n_tar)];
+            const double d = dist2(qp.x, qp.y, t.x, t.y);
+            const bool c = d < bd;
+            f |= c && !(d * kTieAbove < bd);
+            bd = fmin(bd, d);                                        // NaN never lowers it
+            bj = c ? j : bj;
+        }
+    }
+    jf = bj | (f ? (int)0x80000000 : 0);
+    team_merge<0xB1>(bd, jf);     // quad_perm [1,0,3,2]
+    team_merge<0x4E>(bd, jf);     // quad_perm [2,3,0,1]
+    team_merge<0x141>(bd, jf);    // row_half_mirror
+    team_merge<0x140>(bd, jf);    // row_mirror
+}
+
+template <int UNROLL>
+__device__ __forceinline__ void nn_listed(const double2 *__restrict__ tarP, int n_tar, const PolarGeo &geo, double2 *qlist,
+                                          const int *qseed, int nq)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4;
+    for (int base = (threadIdx.x >> 6) * 64; base < nq; base += blockDim.x) {     // wave-uniform
+        const int e = base + lane;
+        const bool act = e < nq;
+        const double2 qp = qlist[act ? e : nq - 1];
+        double d2;
+        int j;
+        bool big, amb;
+        nn_polar<UNROLL, true>(tarP, n_tar, qp.x, qp.y, qseed[act ? e : nq - 1], act, geo, kPolarMaxListed, true, d2, j, big, amb);
+        if (act && !big) qlist[e] = make_double2(d2, __hiloint2double(0, j | (amb ? (int)0x80000000 : 0)));
+        unsigned long long left = __ballot(big);
+        while (left != 0ull) {                                       // four of the remaining queries, one per row
+            int src = 0, cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (left != 0ull) {
+                    const int l = __ffsll((long long)left) - 1;
+                    left &= left - 1ull;
+                    src = row == k ? l : src;
+                    cnt = k + 1;
+                }
+            }
+            const bool valid = row < cnt;
+            double bd;
+            int jf;
+            nn_row(tarP, n_tar, qlist[base + src], bd, jf);           // (rows without a query repeat lane 0's entry)
+            if (valid && (lane & 15) == 0) qlist[base + src] = make_double2(bd, __hiloint2double(0, jf));
+        }
+    }
 }
 
 // LDS image of the target: float64 (x, y) pairs padded with NaN points to a whole number
@@ -635,9 +781,12 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // ---------------------------------------------------------------------------------
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
-constexpr int kIcpExtraLds = 16 + 2 * 4 * 8;   // polar_probe words + the collapsed-set exchange (two parities)
+constexpr int kIcpExtraLds = 32;               // polar_probe words, count of listed queries, re-do flag
 __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
-constexpr int kIcpRedDoubles = 2 * kMaxWaves * 8;   // cross-wave stage of the reductions, two alternating buffers
+// cross-wave stage of the reductions ([2][nwaves][10] doubles: nine values, padded to whole 16 bytes) and of the collapsed-set
+// test ([2][nwaves][4]: matched point of the wave's first query, "this wave saw another"), two alternating buffers each
+constexpr int kRedStride = 10;
+__host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double); }
 
 template <typename T, int QPT, int UNROLL, bool PROBE, bool EXACT>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
@@ -658,13 +807,15 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     const bool has_p = a.polar_copy != 0;
     const size_t p_bytes = has_p ? icp_polar_bytes(a.n_tar) : 0;
     double2 *tarP = has_p ? reinterpret_cast<double2 *>(smem + nn_lds_bytes(a.n_tar)) : nullptr;   // [n_tar + kPolarTail]
-    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + p_bytes);             // [2][kMaxWaves][8]
-    unsigned *geo = reinterpret_cast<unsigned *>(red + kIcpRedDoubles);                          // [4] polar_probe; geo[3]: source set collapsed
-    double *cref = reinterpret_cast<double *>(geo + 4);                                          // [2][4]: matched point of query 0, "all the same" flag
-    char *guard = smem + nn_lds_bytes(a.n_tar) + p_bytes + kIcpRedDoubles * sizeof(double) + kIcpExtraLds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + p_bytes);             // [2][nwaves][kRedStride]
+    double *cref = red + 2 * nwaves * kRedStride;                                                // [2][nwaves][4]
+    unsigned *geo = reinterpret_cast<unsigned *>(cref + 2 * nwaves * 4);                          // [8] polar_probe; geo[3]: source set collapsed; geo[4]: queries listed for the teams; geo[5]: re-do flag
+    double2 *qlist = reinterpret_cast<double2 *>(geo + 8);                                      // [a.team_cap] nn_listed
+    int *qseed = reinterpret_cast<int *>(qlist + a.team_cap);                                    // [a.team_cap]
+    char *guard = reinterpret_cast<char *>(qseed + a.team_cap);
     lds_guard_fill(guard);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     const long be = (long)b + (a.ppt ? b / a.ppt : 0);
     const int n_src = a.n_src, n_tar = a.n_tar;
@@ -677,7 +828,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         src.pts = static_cast<const T *>(a.src) + be * a.src_stride;
     }
 
-    if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; }
+    if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; geo[4] = 0u; geo[5] = 0u; }
     stage_points(tar, n_tar, tarL, tarP);
     __syncthreads();                                                 // (geo is initialised for the probe)
     ISTAMP(10);
@@ -737,22 +888,44 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     const double dn = (double)n_src;
     const LaneSel ls = lane_sel(lane);
     ISTAMP(14);
-    double pre_error = 0.0, mean_error = 0.0;
+    double pre_error = 0.0, mean_error = 0.0, pcx = 0.0, pcy = 0.0;
     int iters = 0, par = 0;
     bool amb_any = false;
-    for (int it = 0; it < a.max_iter; ++it) {
-        double mx[QPT], my[QPT];
-        double v[5] = {0, 0, 0, 0, 0};
+    // one iteration; FIRST: the instance for iteration 0 (the only one that lists queries for the lane teams, and the
+    // loop behind it stays the code it was); returns true when the solve has converged (icp.py:76-77)
+    auto iterate = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        double mx[QPT], my[QPT], dq[QPT];
+        // first iteration over a scan: queries without a usable beam window are listed (nn_listed)
+        const bool team_it = FIRST && !EXACT && a.team_cap > 0 && pg.inv_db > 0.0f;
+        int slot[QPT];
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             double d2; int j;
             bool amb = false;
+            slot[q] = -1;
             if (EXACT) {
                 const NNHit h = nn_exact(has_p ? tarP : tarL, !has_p, ok[q] ? n_tar : 0, sx[q], sy[q]);
                 d2 = h.d2; j = h.j;
             } else if (pg.inv_db > 0.0f) {                           // wave-uniform: the target is a scan
                 bool big;
-                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, d2, j, big, amb);          // icp.py:67
+                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg,
+                                        team_it ? kPolarMaxFirst : (PROBE ? kPolarMax : kPolarMaxLone), !team_it, d2, j, big, amb);          // icp.py:67
+                if (FIRST && team_it) {
+                    const unsigned long long bm = __ballot(big);
+                    if (bm != 0ull) {
+                        int base = 0;
+                        if (lane == 0) base = (int)atomicAdd(&geo[4], (unsigned)__popcll(bm));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+                        if (big && pos < a.team_cap) {
+                            slot[q] = pos;
+                            qlist[pos] = make_double2(sx[q], sy[q]);
+                            qseed[pos] = seed[q];
+                            big = false;                             // (a list that is full leaves the rest to the box search)
+                        }
+                    }
+                }
                 // The few queries without a good match (newly visible surfaces; they come in runs of
                 // neighbouring beams: measured 1.3 % of the queries, in 10 % of the wave-queries, 8 lanes at
                 // a time) take the box search.  Tried and dropped: scanning the whole cloud for them
@@ -761,60 +934,119 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
                 ISTAMP_BIG(it, big);
                 if (__any(big)) {
                     double d2b; int jb; bool ambb;
-                    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, big, d2b, jb, ambb);
+                    nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, big, d2b, jb, ambb);
                     d2 = big ? d2b : d2;
                     j = big ? jb : j;
                     amb = big ? ambb : amb;
                 }
             } else {
-                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], it == 0, ok[q], d2, j, amb);   // icp.py:67
+                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, ok[q], d2, j, amb);   // icp.py:67
             }
             amb_any |= amb;                                          // -> a.redo[b]: the EXACT launch re-does this pair
             seed[q] = j;                                             // next iteration's guess
             double2 m = has_p ? tarP[j] : tarL[tslot(j)];
             mx[q] = m.x; my[q] = m.y;
-            double dist = (d2 < INFINITY) ? sqrt(d2) : 0.0;         // never-won query: distance 0 (:97)
-            if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dist; }
+            dq[q] = (d2 < INFINITY) ? sqrt(d2) : 0.0;               // never-won query: distance 0 (:97)
         }
-        // Two passes, as the reference (centroids, then centred products, icp.py:154-160): when
-        // every source point matches the same target the centred products are exactly zero and
-        // R falls back to the identity, which one-pass raw moments would turn into rounding noise.
-        ISTAMP(it == 0 ? 6 : 1);
-        par ^= 1;
-        double *cr = cref + 4 * (it & 1);          // alternates per iteration: two barriers lie between a slot's reuse
-        if (nwaves > 1 && tid == 0) { cr[0] = mx[0]; cr[1] = my[0]; cr[2] = 1.0; }   // (query 0 of thread 0 always exists)
-        // sums of the five quantities over the pair (transposed reduction: lane l ends up with the total
-        // of value idx8(l)), ONE division sequence for all of them, then five broadcasts
-        double cax, cay, cbx, cby;
-        {
-            const double v8[8] = {v[0], v[1], v[2], v[3], v[4], 0.0, 0.0, 0.0};
-            const double tot = block_total(wave_reduce8(v8, ls), ls.idx8, red + par * kMaxWaves * 8, nwaves, wave, lane);
-            const double qv = tot / dn;                              // icp.py:154-155, :75
-            cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
-            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7
-        }
-        ISTAMP(it == 0 ? 7 : 2);
-        double w[4] = {0, 0, 0, 0};
-        // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above
-        const double m0x = nwaves > 1 ? cr[0] : readlane_f64(mx[0], 0), m0y = nwaves > 1 ? cr[1] : readlane_f64(my[0], 0);
-        bool differs = false;
+        if (FIRST && team_it) {
+            __syncthreads();
+            nn_listed<UNROLL>(tarP, n_tar, pg, qlist, qseed, min((int)geo[4], a.team_cap));
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-            if (ok[q]) {
-                double aax = sx[q] - cax, aay = sy[q] - cay, bbx = mx[q] - cbx, bby = my[q] - cby;
-                w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;   // :160
-                differs |= !(mx[q] == m0x && my[q] == m0y);
+            for (int q = 0; q < QPT; ++q) {
+                if (slot[q] >= 0) {
+                    const double2 rs = qlist[slot[q]];
+                    const int jf = __double2loint(rs.y), j = jf & 0x7fffffff;
+                    amb_any |= jf < 0;
+                    seed[q] = j;
+                    const double2 m = tarP[j];
+                    mx[q] = m.x; my[q] = m.y;
+                    dq[q] = (rs.x < INFINITY) ? sqrt(rs.x) : 0.0;
+                }
             }
         }
-        if (nwaves > 1 && differs) cr[2] = 0.0;
+        // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above.  Every wave
+        // compares its matches with that of its first query (which always exists) and leaves point and verdict in LDS
+        // ahead of the iteration's first barrier; behind it the waves' points are compared with one another.
         par ^= 1;
+        double *cr = cref + par * nwaves * 4;
+        bool wave_differs;
         {
-            const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * kMaxWaves * 8, nwaves, wave, lane);
-            w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
+            const double m0x = readlane_f64(mx[0], 0), m0y = readlane_f64(my[0], 0);
+            bool differs = false;
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) differs |= ok[q] && !(mx[q] == m0x && my[q] == m0y);
+            wave_differs = __any(differs);
+            if (nwaves > 1 && lane == 0) { cr[4 * wave] = m0x; cr[4 * wave + 1] = m0y; cr[4 * wave + 2] = wave_differs ? 1.0 : 0.0; }
         }
-        ISTAMP(it == 0 ? 8 : 3);
-        const bool tar_collapsed = nwaves > 1 ? cr[2] != 0.0 : !__any(differs);
-        if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+        auto targets_collapsed = [&]() -> bool {                     // (call behind the barrier)
+            if (nwaves == 1) return !wave_differs;
+            const double *mine = cr + 4 * min(lane, nwaves - 1);
+            return !__any(mine[2] != 0.0 || !(mine[0] == cr[0] && mine[1] == cr[1]));
+        };
+        double cax, cay, cbx, cby, w[4];
+        if (FIRST || !kOnePass) {
+            // Two passes, as the reference (centroids, then centred products, icp.py:154-160).
+            double v[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < QPT; ++q)
+                if (ok[q]) { v[0] += sx[q]; v[1] += sy[q]; v[2] += mx[q]; v[3] += my[q]; v[4] += dq[q]; }
+            ISTAMP(FIRST ? 6 : 1);
+            // sums of the five quantities over the pair (transposed reduction: lane l ends up with the total
+            // of value idx8(l)), ONE division sequence for all of them, then five broadcasts
+            {
+                const double v8[8] = {v[0], v[1], v[2], v[3], v[4], 0.0, 0.0, 0.0};
+                const double tot = block_total(wave_reduce8(v8, ls), ls.idx8, red + par * nwaves * kRedStride, nwaves, wave, lane);
+                const double qv = tot / dn;                          // icp.py:154-155, :75
+                cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
+                mean_error = readlane_f64(qv, 7);                    // value 4 lives in lane 7
+            }
+            ISTAMP(FIRST ? 7 : 2);
+            const bool tar_collapsed = targets_collapsed();
+            w[0] = w[1] = w[2] = w[3] = 0.0;
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) {
+                if (ok[q]) {
+                    double aax = sx[q] - cax, aay = sy[q] - cay, bbx = mx[q] - cbx, bby = my[q] - cby;
+                    w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;   // :160
+                }
+            }
+            par ^= 1;
+            {
+                const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
+                w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
+            }
+            ISTAMP(FIRST ? 8 : 3);
+            if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+        } else {
+            // From the second iteration on: ONE pass and one barrier.  The update of the iteration before moved the
+            // source's centroid onto the centroid of its matches (t = c_B - R c_A), so that point p is within rounding
+            // of this iteration's source centroid and close to the new matches': sums and products are formed about p
+            // and the exact centroids and centred products follow algebraically,
+            //   c_A = p + S_a / N,  c_B = p + S_b / N,  W = sum (b - p)(a - p)^T - S_b S_a^T / N,
+            // with S_a = sum (a - p) at rounding level - the correction is of the order of the last place of W.
+            double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) {
+                if (ok[q]) {
+                    const double dax = sx[q] - pcx, day = sy[q] - pcy, dbx = mx[q] - pcx, dby = my[q] - pcy;
+                    u[0] += dax; u[1] += day; u[2] += dbx; u[3] += dby; u[4] += dq[q];
+                    u[5] += dbx * dax; u[6] += dbx * day; u[7] += dby * dax; u[8] += dby * day;
+                }
+            }
+            ISTAMP(1);
+            const double tot = block_total<9>(wave_reduce9(u, ls), ls.idx16, red + par * nwaves * kRedStride, nwaves, wave, lane);
+            const double qv = tot / dn;                              // icp.py:154-155, :75
+            const double qax = readlane_f64(qv, 0), qay = readlane_f64(qv, 1);
+            cax = pcx + qax; cay = pcy + qay;
+            cbx = pcx + readlane_f64(qv, 2); cby = pcy + readlane_f64(qv, 3);
+            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7, values 5..7 in lanes 6, 5, 4, value 8 in lane 15
+            const double sbx = readlane_f64(tot, 2), sby = readlane_f64(tot, 3);
+            w[0] = readlane_f64(tot, 6) - sbx * qax; w[1] = readlane_f64(tot, 5) - sbx * qay;
+            w[2] = readlane_f64(tot, 4) - sby * qax; w[3] = readlane_f64(tot, 15) - sby * qay;
+            ISTAMP(3);
+            if (targets_collapsed() || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+        }
         Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {                              // src = T.src (:71)
@@ -822,18 +1054,26 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             double ny = r.s * sx[q] + r.c * sy[q] + r.ty;
             sx[q] = nx; sy[q] = ny;
         }
+        pcx = cbx; pcy = cby;                                        // the centroid the source now has (up to rounding)
         ++iters;
-        ISTAMP(it == 0 ? 9 : 4);
-        if (fabs(pre_error - mean_error) < a.tol) break;             // :76-77
+        ISTAMP(FIRST ? 9 : 4);
+        if (fabs(pre_error - mean_error) < a.tol) return true;       // :76-77
         pre_error = mean_error;
-    }
+        return false;
+    };
+    if (a.max_iter > 0 && !iterate(std::true_type{}, 0))
+        for (int it = 1; it < a.max_iter; ++it)
+            if (iterate(std::false_type{}, it)) break;
 
+    // (a pair in which some lane saw a best undercut its predecessor by less than a class of equal distances is
+    // re-done by the EXACT launch: the flag travels through LDS, behind the barrier of the sums below)
+    if (!EXACT && amb_any) geo[5] = 1u;
     // final T = getTransform(A_original, src_final) (icp.py:81)
     double v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < QPT; ++q)
         if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
-    block_sum<4>(v, red + (par ^= 1) * kMaxWaves * 8, nwaves, wave, lane);
+    block_sum<4>(v, red + (par ^= 1) * nwaves * kRedStride, nwaves, wave, lane);
     double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
     double w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -843,13 +1083,10 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
         }
     }
-    block_sum<4>(w, red + (par ^= 1) * kMaxWaves * 8, nwaves, wave, lane);
+    block_sum<4>(w, red + (par ^= 1) * nwaves * kRedStride, nwaves, wave, lane);
     if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
-    if (a.redo) {
-        const int flag = EXACT ? 0 : __syncthreads_or(amb_any ? 1 : 0);
-        if (tid == 0) a.redo[b] = flag;
-    }
     if (tid == 0) {
+        if (a.redo) a.redo[b] = EXACT ? 0 : (int)geo[5];
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = a.T_out + 9 * (long)b;
         To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
@@ -883,11 +1120,23 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
     int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
     if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
-    const size_t lds_base = nn_lds_bytes(a.n_tar) + kIcpRedDoubles * sizeof(double) + kIcpExtraLds + kLdsGuard;
+    if (qpt > 4) qpt = 8;                     // the shapes that exist: 1, 2, 3, 4, 8 queries per lane
+    const int block = icp_block(a.n_src, qpt);
+    const size_t lds_base = nn_lds_bytes(a.n_tar) + icp_red_bytes(block / kWave) + kIcpExtraLds + kLdsGuard;
     // second, unpadded copy of the target for the beam-window search: only for scans, and only while both copies fit
     // (up to 4 544 beams; larger scans, up to the documented 8 192, and point clouds go by the box search alone)
     a.polar_copy = (a.ranges && lds_base + icp_polar_bytes(a.n_tar) <= 160 * 1024) ? 1 : 0;
     size_t lds = lds_base + (a.polar_copy ? icp_polar_bytes(a.n_tar) : 0);
+    // the list of first-iteration queries without a usable window (nn_listed): room for a quarter of the queries - on
+    // the benchmark scans a tenth of them is listed - as far as the CU's LDS goes; a full list leaves the rest to the box search
+    a.team_cap = 0;
+    if (a.polar_copy && a.team_mode == 0) {
+        long cap = ((a.n_src + 3) / 4 + 15) / 16 * 16;
+        const long room = ((long)160 * 1024 - (long)lds) / (long)(sizeof(double2) + sizeof(int));
+        cap = cap < room ? cap : room / 16 * 16;
+        a.team_cap = cap > 0 ? (int)cap : 0;
+    }
+    lds += (size_t)a.team_cap * (sizeof(double2) + sizeof(int));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
 #define SLAM_ICP_CASE(Q, U, P)                                                                                  \
@@ -897,14 +1146,14 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q, U, P, false>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);                 \
+        SLAM_LAUNCH((k_icp<T, Q, U, P, false>), grid, dim3(block), lds, s, a);                 \
         if (a.redo) {                                                                                           \
             if (lds > 64 * 1024) {                                                                              \
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, 2, false, true>), \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
                 if (e != hipSuccess) return e;                                                                  \
             }                                                                                                   \
-            SLAM_LAUNCH((k_icp<T, Q, 2, false, true>), grid, dim3(icp_block(a.n_src, Q)), lds, s, a);          \
+            SLAM_LAUNCH((k_icp<T, Q, 2, false, true>), grid, dim3(block), lds, s, a);          \
         }                     \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid

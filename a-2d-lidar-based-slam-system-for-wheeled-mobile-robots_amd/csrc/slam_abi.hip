@@ -88,6 +88,7 @@ struct slam_ctx {
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
     int grid_split = -1;  // window mode: two workgroups per group, one per direction half (-1: when the launch cannot fill the chip)
     int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
+    int icp_team = 0;     // first-iteration queries without a beam window: 0 = searched by lane teams, 1 = by the box search
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
     // a second stream, so the map stage of one replay overlaps the scan matching of the next.
     int pipeline = 0;
@@ -459,6 +460,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3 || value == 4, "grid_mode is 0..4"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
     else if (!strcmp(name, "grid_split")) { REQUIRE(value == -1 || value == 0 || value == 1, "grid_split is -1, 0 or 1"); c->grid_split = (int)value; }
+    else if (!strcmp(name, "icp_team")) { REQUIRE(value == 0 || value == 1, "icp_team is 0 or 1"); c->icp_team = (int)value; }
     else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
         REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
@@ -639,7 +641,7 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     a.ppt = 0;
     a.B = B; a.n_tar = n_tar; a.n_src = n_src; a.max_iter = max_iter; a.tol = tol;
     a.T_out = T_out; a.iters_out = iters_out; a.err_out = mean_err_out;
-    a.status = c->status; a.qpt_pref = c->icp_qpt;
+    a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
     TRY(redo_flags(c, B, &a.redo));
     Timed t(c, SLAM_K_ICP);
     HIPCHK(launch_icp(a, dtype, c->stream));
@@ -1119,7 +1121,7 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         a.ppt = n_scan - 1;
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
-        a.status = c->status; a.qpt_pref = c->icp_qpt;
+        a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
         TRY(redo_flags(c, pairs, &a.redo));
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
@@ -1216,7 +1218,7 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         a.ppt = 0;
         a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
-        a.status = c->status; a.qpt_pref = c->icp_qpt;
+        a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
         TRY(redo_flags(c, P, &a.redo));
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));

@@ -246,6 +246,38 @@ def test_replay_largest_scans_vs_oracle(slam, syn, beams):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["replay", "jumps", "random", "dense", "five"])
+def test_listed_first_iteration_queries_match_the_box_search(slam, syn, kind):
+    """First-iteration queries without a usable beam window are listed in LDS and searched apart from the lanes that own
+    them (context option icp_team 0: re-guess + window per listed query, exhaustive rows of 16 lanes for what is
+    left), or by the box search of their own lane (icp_team 1): bit-identical T and iteration counts, and both equal
+    the oracle.  'jumps': every other beam of the source scans at an unrelated range (half the queries listed: the list
+    overflows and the rest takes the box search); 'random': no surface at all (every listed query ends in the
+    exhaustive rows); 'dense': 1 080 beams; 'five': a five-beam scan (rows mostly empty)."""
+    rng = np.random.default_rng(77)
+    if kind == "dense":
+        ranges = syn.make_replay(6, 1080, seed=23, stride=5, room_scale=2.0).ranges
+    elif kind == "five":
+        ranges = rng.uniform(0.5, 6.0, size=(9, 5)).astype(np.float32)
+    else:
+        ranges = syn.make_replay(24, 360, seed=22, stride=5).ranges.copy()
+        if kind == "jumps":
+            ranges[1::2, ::2] = rng.uniform(0.5, 20.0, size=ranges[1::2, ::2].shape).astype(np.float32)
+        if kind == "random":
+            ranges = rng.uniform(0.3, 25.0, size=ranges.shape).astype(np.float32)
+    out = []
+    for team in (0, 1):
+        ctx = slam.Context(0)
+        ctx.set_option("icp_team", team)
+        out.append(slam.replay_host(ranges, AMIN, AMAX, context=ctx))
+        ctx.close()
+    (p0, T0, it0), (p1, T1, it1) = out
+    assert np.array_equal(it0, it1) and np.array_equal(T0, T1) and np.array_equal(p0, p1)
+    oposes, oT, oit, _ = co.replay(ranges, AMIN, AMAX, None, threads=8)
+    assert np.array_equal(it0, oit)
+    assert np.max(np.abs(p0 - oposes)) < FTOL and np.max(np.abs(T0 - oT.reshape(T0.shape))) < FTOL
+
+
 def test_icp_max_iter_zero_and_tol_zero(slam, syn):
     pair = syn.scan_pair(120, seed=1)
     tar, src = co.laser_to_points(pair.ranges[0], AMIN, AMAX), co.laser_to_points(pair.ranges[1], AMIN, AMAX)
