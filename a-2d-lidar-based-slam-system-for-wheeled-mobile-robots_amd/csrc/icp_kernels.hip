@@ -437,7 +437,7 @@ constexpr int kPolarMax = 32;     // widest window (beams) the polar search take
 // as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
 // lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
 constexpr int kPolarMaxLone = 96;
-constexpr int kPolarMaxFirst = 32;            // ... and in a first iteration whose wider ones are listed (nn_listed),
+constexpr int kPolarMaxFirst = 16;            // ... and in a first iteration whose wider ones are listed (nn_listed: 16 / 24 / 32 within 1 %),
 constexpr int kPolarMaxListed = 48;           // where a window may be this wide after the re-guess
 constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
 constexpr bool kOnePass = true;               // iterations after the first: centroids and centred products in one reduction (k_icp)
@@ -691,15 +691,15 @@ struct Cloud {
 // Is the target a usable scan?  Beam directions must be unit vectors, ordered by angle with
 // neighbours less than 30 degrees apart, spanning at most one turn (plus half a beam), and no
 // range may be negative.  One workgroup-wide pass over the trig tables per pair (they are shared
-// by all pairs of a launch and sit in L2).  geo[0]: smallest cross product of neighbouring
-// directions as float bits (a lower bound of their angle: asin(x) >= x), geo[1]: ok flag,
-// geo[2]: upper bound of the span.
+// by all pairs of a launch and sit in L2).  Every wave leaves its part in slots[wave]: [0] smallest
+// cross product of neighbouring directions as float bits (a lower bound of their angle: asin(x) >= x),
+// [1] upper bound of the span it saw (float bits), [2] ok flag; polar_combine() puts them together behind
+// a barrier.  (No atomics, no initialisation to order against: the probe runs ahead of the pair's first
+// barrier, its loads in flight together with those that stage the target.)
 template <typename T>
-__device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsigned *geo)
+__device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsigned *slots)
 {
-    // per-lane partials, one butterfly per wave, one LDS atomic per wave and word (an atomic per
-    // beam is turned by the compiler into a serial loop over the 64 lanes: 12 % of a pair's
-    // set-up time when it was written that way)
+    // per-lane partials, one butterfly per wave
     unsigned mn = 0x7f800000u;
     float sum = 0.0f;
     bool bad = false;
@@ -722,11 +722,33 @@ __device__ __forceinline__ void polar_probe(const Cloud<T> &tar, int n_tar, unsi
         mn = min(mn, (unsigned)__shfl_xor((int)mn, off));
         sum += __shfl_xor(sum, off);
     }
+    const bool wave_bad = __any(bad);
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&geo[0], mn);
-        atomicAdd(reinterpret_cast<float *>(&geo[2]), sum * 1.00001f);       // (the order of the additions is not fixed: pad)
+        unsigned *s = slots + 4 * (threadIdx.x >> 6);
+        s[0] = mn;
+        s[1] = __float_as_uint(sum * 1.00001f);
+        s[2] = wave_bad ? 0u : 1u;
     }
-    if (bad) geo[1] = 0u;
+}
+
+struct PolarProbe { float dmin, span; bool ok; };
+__device__ __forceinline__ PolarProbe polar_combine(const unsigned *slots, int nwaves)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned mn = 0x7f800000u, okw = 1u;
+    float sum = 0.0f;
+    if (lane < nwaves) { mn = slots[4 * lane]; sum = __uint_as_float(slots[4 * lane + 1]); okw = slots[4 * lane + 2]; }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {                          // (at most kMaxWaves = 16 slots)
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, off));
+        sum += __shfl_xor(sum, off);
+        okw &= (unsigned)__shfl_xor((int)okw, off);
+    }
+    PolarProbe r;
+    r.dmin = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)mn));
+    r.span = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum * 1.00001f)));
+    r.ok = __builtin_amdgcn_readfirstlane((int)okw) != 0;
+    return r;
 }
 
 template <typename T>
@@ -828,15 +850,9 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         src.pts = static_cast<const T *>(a.src) + be * a.src_stride;
     }
 
-    if (threadIdx.x == 0) { geo[0] = 0x7f800000u; geo[1] = a.ranges ? 1u : 0u; geo[2] = 0u; geo[3] = 1u; geo[4] = 0u; geo[5] = 0u; }
-    stage_points(tar, n_tar, tarL, tarP);
-    __syncthreads();                                                 // (geo is initialised for the probe)
-    ISTAMP(10);
-    stage_boxes(n_tar, tarL, boxes, boxes4);
-    ISTAMP(11);
-    if (a.ranges && has_p) polar_probe(tar, n_tar, geo);
-    ISTAMP(12);
+    if (threadIdx.x == 0) { geo[3] = 1u; geo[4] = 0u; geo[5] = 0u; }
 
+    // the source points first: their loads are in flight together with those that stage the target
     double sx[QPT], sy[QPT], ax[QPT], ay[QPT];
     int seed[QPT];
     bool ok[QPT];
@@ -856,7 +872,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
         sy[q] = ay[q] = y;
         seed[q] = i;                             // first guess: the same beam index
     }
-    ISTAMP(13);
+    bool src_differs = false;
     {
         // Collapsed sets (every point of a set is ONE point): W = BB^T.AA is mathematically zero and
         // the canonical answer is R = I (the SVD of a zero matrix), t = centroid_B - centroid_A.  The
@@ -867,23 +883,34 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             const double *p = a.prior + 6 * (long)b;
             p0 = make_double2(p[0] * p0.x + p[1] * p0.y + p[2], p[3] * p0.x + p[4] * p0.y + p[5]);
         }
-        bool differs = false;
 #pragma unroll
-        for (int q = 0; q < QPT; ++q) differs |= ok[q] && !(ax[q] == p0.x && ay[q] == p0.y);
-        if (differs) geo[3] = 0u;
+        for (int q = 0; q < QPT; ++q) src_differs |= ok[q] && !(ax[q] == p0.x && ay[q] == p0.y);
     }
-    __syncthreads();
-    const bool src_collapsed = geo[3] != 0u;
+    ISTAMP(13);
+    stage_points(tar, n_tar, tarL, tarP);
+    const bool probed = a.ranges && has_p;
+    unsigned *pslots = reinterpret_cast<unsigned *>(cref);           // [nwaves][4]: the iterations use this space later
+    if (probed) polar_probe(tar, n_tar, pslots);
+    __syncthreads();                                                 // (geo is initialised)
+    ISTAMP(10);
+    if (src_differs) geo[3] = 0u;
     // the target is a scan with usable beam geometry: nearest neighbours by beam window (nn_polar)
     PolarGeo pg;
     {
-        const float dmin = __uint_as_float(geo[0]), span = __uint_as_float(geo[2]);
+        PolarProbe pp{1.0f, 0.0f, false};
+        if (probed) pp = polar_combine(pslots, nwaves);
+        const float dmin = pp.dmin, span = pp.span;
         // (beams closer together than 1e-5 rad are no usable geometry: the window's index bound (dhi + alpha) * inv_db
         // must stay far inside the int range)
-        const bool polar = has_p && geo[1] != 0u && n_tar >= 2 && dmin >= 1e-5f && dmin < 1.0f && span <= 6.2831855f + 0.5f * dmin;
+        const bool polar = probed && pp.ok && n_tar >= 2 && dmin >= 1e-5f && dmin < 1.0f && span <= 6.2831855f + 0.5f * dmin;
         pg.inv_db = polar ? __fdividef(1.000002f, dmin) : 0.0f;
         pg.slack = StoreSlack<T>::ang;
     }
+    ISTAMP(12);
+    stage_boxes(n_tar, tarL, boxes, boxes4);
+    ISTAMP(11);
+    __syncthreads();
+    const bool src_collapsed = geo[3] != 0u;
 
     const double dn = (double)n_src;
     const LaneSel ls = lane_sel(lane);
@@ -1127,11 +1154,11 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     // (up to 4 544 beams; larger scans, up to the documented 8 192, and point clouds go by the box search alone)
     a.polar_copy = (a.ranges && lds_base + icp_polar_bytes(a.n_tar) <= 160 * 1024) ? 1 : 0;
     size_t lds = lds_base + (a.polar_copy ? icp_polar_bytes(a.n_tar) : 0);
-    // the list of first-iteration queries without a usable window (nn_listed): room for a quarter of the queries - on
-    // the benchmark scans a tenth of them is listed - as far as the CU's LDS goes; a full list leaves the rest to the box search
+    // the list of first-iteration queries without a usable window (nn_listed): room for half of the queries - on the
+    // benchmark scans a fifth of them is listed - as far as the CU's LDS goes; a full list leaves the rest to the box search
     a.team_cap = 0;
     if (a.polar_copy && a.team_mode == 0) {
-        long cap = ((a.n_src + 3) / 4 + 15) / 16 * 16;
+        long cap = ((a.n_src + 1) / 2 + 15) / 16 * 16;
         const long room = ((long)160 * 1024 - (long)lds) / (long)(sizeof(double2) + sizeof(int));
         cap = cap < room ? cap : room / 16 * 16;
         a.team_cap = cap > 0 ? (int)cap : 0;
