@@ -5,20 +5,22 @@
 // Functional spec = the reference's Python (paths relative to /root/reference,
 // W12m = "W12_LiDAR SLAM/w12-mapping/course_agv_slam/scripts"):
 //   ICP.process      W12m/icp.py:38-88      -> k_icp
-//   ICP.findNearest  W12m/icp.py:90-114     -> nn_search / k_nn
+//   ICP.findNearest  W12m/icp.py:90-114     -> nn_polar / nn_listed / nn_search / nn_exact / k_nn
 //   ICP.getTransform W12m/icp.py:149-179    -> kabsch_from_sums / k_kabsch
 //   laserToNumpy     W12m/slam_ekf.py:115-123 -> k_scan_to_points
 //   publishResult    W12m/icp.py:185-190    -> k_pose_compose
 //
-// Design (DESIGN.md "K2"): one workgroup per scan pair, one lane per query point.  The
-// target cloud is staged once in LDS as float64 (x,y) pairs and every lane sweeps it with
-// broadcast ds_read_b128; the source point, its original copy and the running best live
-// in registers for the whole solve, so HBM sees each point once.  All arithmetic is
-// float64 (the reference is float64 and a float32 distance would flip near-tied
-// neighbours, moving the pose by ~1e-4); gfx950 issues f64 FMA at half
-// the f32 rate, which still leaves the path >100x above its throughput target.
-// The library is compiled with -ffp-contract=off: fused multiply-adds appear only where
-// written as fma().
+// Design (DESIGN.md "K2"): one workgroup per scan pair, one to three query points per lane.  The
+// target is staged once in LDS as float64 (x, y) pairs; the source points, their original copies
+// and the running best live in registers for the whole solve, so HBM sees each range once.
+// Nearest neighbours of a scan are searched in a window of beam indices around a guess (nn_polar),
+// first-iteration queries whose guess bounds nothing are compacted into an LDS list and searched
+// apart from their lanes (nn_listed), the box search (nn_search) takes what remains.  The first
+// iteration forms centroids and centred products in two reductions as the reference does, the later
+// ones in one reduction about the previous matches' centroid.  All arithmetic is float64 (the
+// reference is float64 and a float32 distance would flip near-tied neighbours, moving the pose by
+// ~1e-4).  The library is compiled with -ffp-contract=off: fused multiply-adds appear
+// only where written as fma().
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -298,7 +300,7 @@ __device__ __forceinline__ double dist2(double sx, double sy, double tx, double 
 // square (no square root per candidate) and watch for the one event that can make the two orderings
 // disagree: a candidate replacing a best that is less than 2^-50 above it (a class of equal roots spans
 // at most 2^-51 of its value).  k_nn re-does the query of a lane that saw one the reference's way over the
-// whole target (nn_exact); k_icp marks the PAIR (a.redo[b]) and the second launch of the batch re-does it with
+// whole target (nn_exact); k_icp marks the PAIR (an LDS flag) and its workgroup then re-does it with
 // nn_exact in every iteration.  Rare - mathematically tied neighbours of symmetric or quantised scans whose
 // squares round differently - and exact; tests/golden/g10_sqrt_ties.npz holds replays whose iteration count
 // depends on it.
@@ -810,16 +812,13 @@ __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n
 constexpr int kRedStride = 10;
 __host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double); }
 
+// EXACT: the second pass over a pair in which the first saw a best undercut its predecessor by less than a class of
+// equal distances (see "Best"): the same solve with the reference's own nearest-neighbour loop (nn_exact).
+// Returns whether the pair needs that second pass (the same value in every lane; false from the second pass).
 template <typename T, int QPT, int UNROLL, bool PROBE, bool EXACT>
-__global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
+__device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *smem)
 {
-    // EXACT: the second launch of every batch.  It re-does, with the reference's own nearest-neighbour loop
-    // (nn_exact), the pairs in which the first launch saw a best undercut its predecessor by less than a class
-    // of equal distances (a.redo[b], see "Best") - none on noisy scans, a few per cent of the pairs on scans
-    // with quantised ranges - and returns at once for all others.
-    if (EXACT && !a.redo[blockIdx.x]) return;
     ISTAMP_DECL;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblocks = nn_blocks(a.n_tar);
     double2 *tarL = reinterpret_cast<double2 *>(smem);                                           // [nblocks * kNNStride]
     Box *boxes = reinterpret_cast<Box *>(smem + (size_t)nblocks * kNNStride * sizeof(double2));  // [padded to x4]
@@ -838,7 +837,6 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     char *guard = reinterpret_cast<char *>(qseed + a.team_cap);
     lds_guard_fill(guard);
 
-    const int b = blockIdx.x;
     const long be = (long)b + (a.ppt ? b / a.ppt : 0);
     const int n_src = a.n_src, n_tar = a.n_tar;
     Cloud<T> tar{nullptr, nullptr, a.cos_t, a.sin_t, n_tar}, src{nullptr, nullptr, a.cos_t, a.sin_t, n_src};
@@ -969,7 +967,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             } else {
                 nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, ok[q], d2, j, amb);   // icp.py:67
             }
-            amb_any |= amb;                                          // -> a.redo[b]: the EXACT launch re-does this pair
+            amb_any |= amb;                                          // -> the pair is re-done (icp_pair<EXACT>)
             seed[q] = j;                                             // next iteration's guess
             double2 m = has_p ? tarP[j] : tarL[tslot(j)];
             mx[q] = m.x; my[q] = m.y;
@@ -1093,7 +1091,7 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
             if (iterate(std::false_type{}, it)) break;
 
     // (a pair in which some lane saw a best undercut its predecessor by less than a class of equal distances is
-    // re-done by the EXACT launch: the flag travels through LDS, behind the barrier of the sums below)
+    // re-done: the flag travels through LDS, behind the barriers of the sums below)
     if (!EXACT && amb_any) geo[5] = 1u;
     // final T = getTransform(A_original, src_final) (icp.py:81)
     double v[4] = {0, 0, 0, 0};
@@ -1113,7 +1111,6 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     block_sum<4>(w, red + (par ^= 1) * nwaves * kRedStride, nwaves, wave, lane);
     if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
     if (tid == 0) {
-        if (a.redo) a.redo[b] = EXACT ? 0 : (int)geo[5];
         Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = a.T_out + 9 * (long)b;
         To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
@@ -1125,6 +1122,21 @@ __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
     ISTAMP(5);
     ISTAMP_END(iters);
     lds_guard_check(guard, a.status);
+    return !EXACT && (nwaves > 1 ? geo[5] != 0u : __any(amb_any));
+}
+
+// k_icp: one workgroup per pair.  None of the pairs of noisy scans and a few per cent of those with quantised ranges
+// need the second pass (icp_pair<EXACT>); the workgroup of such a pair runs it right away - until round 3 a
+// second launch did, which cost every batch 4 us whether or not a pair was flagged.  The second pass overwrites
+// the outputs of the first.  (Registers are the larger of the two passes' needs, not their sum.)
+template <typename T, int QPT, int UNROLL, bool PROBE>
+__global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (icp_pair<T, QPT, UNROLL, PROBE, false>(a, blockIdx.x, smem)) {
+        __syncthreads();                                             // the second pass re-uses the LDS
+        icp_pair<T, QPT, 2, false, true>(a, blockIdx.x, smem);
+    }
 }
 
 static inline int icp_block(int n_src, int qpt)
@@ -1169,19 +1181,11 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
 #define SLAM_ICP_CASE(Q, U, P)                                                                                  \
     {                                                                                                           \
         if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P, false>),                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P>),                      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q, U, P, false>), grid, dim3(block), lds, s, a);                 \
-        if (a.redo) {                                                                                           \
-            if (lds > 64 * 1024) {                                                                              \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, 2, false, true>), \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-                if (e != hipSuccess) return e;                                                                  \
-            }                                                                                                   \
-            SLAM_LAUNCH((k_icp<T, Q, 2, false, true>), grid, dim3(block), lds, s, a);          \
-        }                     \
+        SLAM_LAUNCH((k_icp<T, Q, U, P>), grid, dim3(block), lds, s, a);                                         \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid
     // once per pair - was measured: 12 % fewer instructions, but 0.28 instead of 0.20 ms alone and

@@ -75,7 +75,6 @@ struct slam_ctx {
     Arena staging;   // device copies of host arguments (host-pointer entry points)
     Arena scratch;   // temporaries of *_dev sequences
     Arena tiles;     // recorded walks of the tiled ray cast
-    Arena redo;      // one flag per scan pair: "re-do with the reference's own nearest-neighbour loop" (k_icp)
     char *pinned = nullptr;   // page-locked host block: small calls go through it in one copy each way
     size_t pinned_cap = 0;
     int *status = nullptr;
@@ -166,18 +165,6 @@ T *carve(Arena &a, size_t count)
     }
     a.used = off + count * sizeof(T);
     return reinterpret_cast<T *>(a.base + off);
-}
-
-// flags of the scan-matching launch pair (written by the first kernel for every pair, read and cleared by the second)
-int redo_flags(slam_ctx *c, long B, int32_t **out)
-{
-    size_t need = align_up((size_t)B * sizeof(int32_t));
-    if (need > c->redo.cap) {
-        int rc = arena_reserve(c, c->redo, need);
-        if (rc != SLAM_OK) return rc;
-    }
-    *out = reinterpret_cast<int32_t *>(c->redo.base);
-    return SLAM_OK;
 }
 
 // RAII bracket around the kernel launch(es) of a family: every SLAM_LAUNCH inside it draws a
@@ -430,7 +417,6 @@ int slam_destroy(slam_ctx *c)
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->staging.base) (void)hipFree(c->staging.base);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
-    if (c->redo.base) (void)hipFree(c->redo.base);
     if (c->tiles.base) (void)hipFree(c->tiles.base);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->status) (void)hipFree(c->status);
@@ -642,7 +628,6 @@ int slam_icp_batch_dev(slam_ctx *c, const void *tar, const void *src, int B, int
     a.B = B; a.n_tar = n_tar; a.n_src = n_src; a.max_iter = max_iter; a.tol = tol;
     a.T_out = T_out; a.iters_out = iters_out; a.err_out = mean_err_out;
     a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
-    TRY(redo_flags(c, B, &a.redo));
     Timed t(c, SLAM_K_ICP);
     HIPCHK(launch_icp(a, dtype, c->stream));
     return SLAM_OK;
@@ -1122,7 +1107,6 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
         a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
-        TRY(redo_flags(c, pairs, &a.redo));
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }
@@ -1219,7 +1203,6 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
         a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
-        TRY(redo_flags(c, P, &a.redo));
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }

@@ -92,7 +92,6 @@ struct IcpArgs {
     int32_t *iters_out;        // nullable [B]
     double *err_out;           // nullable [B]
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
-    int32_t *redo = nullptr;   // [B] scratch: pairs the EXACT launch must re-do (see k_icp); null: no second launch
     int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
     int polar_copy = 0;        // set by launch_icp: the kernel carves the unpadded second copy of the target (nn_polar)
     int team_cap = 0;          // set by launch_icp: first-iteration queries the lane teams can take (nn_team), 0: none

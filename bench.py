@@ -239,7 +239,7 @@ def load_pmc(config, kernel):
 # --------------------------------------------------------------------------------------
 class ReplayWorkload:
     """configs[1] / [3] / [4]: per lane a DeviceReplay + map + pmap; a step runs on lane slot % lanes."""
-    family_kernels = {"icp": "k_icp+k_icp_exact", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
+    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args
@@ -349,7 +349,7 @@ class ParticleWorkload:
     consecutive steps (independent: the same scan pair, the same priors) alternate between contexts that each
     own a stream, output buffers and a set of P maps, so that one step's scan matching (vector-issue bound)
     shares the chip with another's ray cast (memory bound)."""
-    family_kernels = {"icp": "k_icp+k_icp_exact", "grid": "k_grid_update_owner8+k_grid_update_owner_redo", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
+    family_kernels = {"icp": "k_icp", "grid": "k_grid_update_owner8+k_grid_update_owner_redo", "compose": "k_pose_step", "finalize": "k_grid_finalize"}
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args
@@ -655,7 +655,7 @@ def roofline_of(args, res):
         roofline["icp_work"] = {"exhaustive_equivalent_distance_evals_per_s": evals / icp_s, "mean_iters": float(iters.mean()),
                                 "note": "equivalent brute-force rate; f64 VALU peak is %.1f TFLOP/s (~%.1e evals/s at 6 flop each)"
                                         % (F64_VALU_PEAK_TFLOPS, F64_VALU_PEAK_TFLOPS * 1e12 / 6)}
-        lds_insts = load_pmc(args.config, "k_icp+k_icp_exact").get("lds_insts_per_launch")
+        lds_insts = load_pmc(args.config, "k_icp").get("lds_insts_per_launch")
         if lds_insts:
             roofline["icp_work"]["lds"] = {"wave_instructions_per_launch": lds_insts, "upper_bound_GBps": lds_insts * 1024.0 / icp_s / 1e9,
                                            "peak_GBps": 256 * 128 * 2.4,

@@ -28,10 +28,6 @@ def short(name):
     n = n.split("(")[0]
     n = n.replace("slam::", "")
     base = n.split("<")[0]
-    # the second launch of every scan-matching batch (k_icp<..., EXACT = true>: re-does the pairs flagged for
-    # distance ties, returns at once for the others) is kept apart from the kernel that does the work
-    if base == "k_icp" and "<" in n and n.rstrip(">").split(",")[-1].strip() == "true":
-        return "k_icp_exact"
     return base
 
 
