@@ -1098,8 +1098,15 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
 #pragma unroll
     for (int q = 0; q < QPT; ++q)
         if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
-    block_sum<4>(v, red + (par ^= 1) * nwaves * kRedStride, nwaves, wave, lane);
-    double cax = v[0] / dn, cay = v[1] / dn, cbx = v[2] / dn, cby = v[3] / dn;
+    // (the reductions of the iterations: transposed wave reduction, one LDS stage, ONE division sequence per stage;
+    // the same sums in the same order as block_sum, and the same quotients)
+    par ^= 1;
+    double cax, cay, cbx, cby;
+    {
+        const double tot = block_total(wave_reduce4(v, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
+        const double qv = tot / dn;
+        cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
+    }
     double w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
@@ -1108,10 +1115,14 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
         }
     }
-    block_sum<4>(w, red + (par ^= 1) * nwaves * kRedStride, nwaves, wave, lane);
+    par ^= 1;
+    {
+        const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
+        w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
+    }
     if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+    const Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);
     if (tid == 0) {
-        Rigid2 r = kabsch_from_sums(cax, cay, cbx, cby, w[0], w[1], w[2], w[3]);
         double *To = a.T_out + 9 * (long)b;
         To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
         To[3] = r.s; To[4] = r.c;  To[5] = r.ty;
