@@ -152,8 +152,8 @@ def test_kernels_pick_what_the_reference_picks(g9, g10):
 @pytest.mark.parametrize("points", ["f64", "f16"])
 def test_distance_ties_in_the_batched_launch_shapes(qpt, points):
     """The launch shapes of large batches (two and three queries per lane: beam-window search with four candidates
-    per trip, the re-guess of useless first guesses, the box search behind them, the second launch that re-does
-    flagged pairs) on a 120-scan staircase stream in which the reference's tie rule decides dozens of queries
+    per trip, the listed first-iteration queries and their re-guess, the box search behind them, the second pass that
+    re-does flagged pairs inside the launch) on a 120-scan staircase stream in which the reference's tie rule decides dozens of queries
     (counted by the oracle): iteration counts exact, transforms to 1e-9, for every pair."""
     from oracle import checks
     slam = pkg()

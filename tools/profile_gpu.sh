@@ -47,5 +47,8 @@ if [ "$CFG" = replay ]; then
     echo "SQ_INSTS_VALU icp_qpt=3" > "$OUT/pmc_6/counters.txt"
 fi
 [ "$CFG" = replay ] && python3 "$R/tools/isa_mix.py" "$OUT/isa_mix.json" > /dev/null
+# the summary first (it puts this run's PMC figures under profiles/ of this copy of the tree), then the plain bench line that
+# reads them, then the summary again to file that line with the rest
+python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG" "$CFG" > /dev/null
 python3 "$R/bench.py" --config $CFG --no-other-configs $STEPS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG" "$CFG"
