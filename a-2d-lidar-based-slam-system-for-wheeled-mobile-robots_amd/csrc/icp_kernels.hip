@@ -807,9 +807,10 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // ---------------------------------------------------------------------------------
 constexpr int kIcpExtraLds = 32;               // polar_probe words, count of listed queries, re-do flag
 __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
-// cross-wave stage of the reductions ([2][nwaves][10] doubles: nine values, padded to whole 16 bytes) and of the collapsed-set
-// test ([2][nwaves][4]: matched point of the wave's first query, "this wave saw another"), two alternating buffers each
-constexpr int kRedStride = 10;
+// cross-wave stage of the reductions ([2][nwaves][9] doubles: the nine values of the one-pass iteration; 144 B a wave, so
+// what follows stays 16-byte aligned) and of the collapsed-set test ([2][nwaves][4]: matched point of the wave's first
+// query, "this wave saw another"), two alternating buffers each
+constexpr int kRedStride = 9;
 __host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double); }
 
 // EXACT: the second pass over a pair in which the first saw a best undercut its predecessor by less than a class of

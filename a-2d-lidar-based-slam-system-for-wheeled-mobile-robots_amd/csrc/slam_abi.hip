@@ -87,7 +87,7 @@ struct slam_ctx {
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
     int grid_split = -1;  // window mode: two workgroups per group, one per direction half (-1: when the launch cannot fill the chip)
     int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
-    int icp_team = 0;     // first-iteration queries without a beam window: 0 = searched by lane teams, 1 = by the box search
+    int icp_team = 0;     // first-iteration queries without a beam window: 0 = listed and searched apart from their lanes (nn_listed), 1 = box search
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
     // a second stream, so the map stage of one replay overlaps the scan matching of the next.
     int pipeline = 0;

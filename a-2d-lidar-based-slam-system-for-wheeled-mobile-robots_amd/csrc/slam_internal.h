@@ -54,7 +54,7 @@ enum : int { kStatusNaN = 1, kStatusOverflow = 2, kStatusGuard = 4 };
 // AddressSanitizer is not available on the target pool; this catches the overrun class that
 // matters here (a region sized too small, e.g. a window row count rounded the wrong way).
 #ifdef SLAM_LDS_GUARD
-constexpr int kLdsGuard = 1024;
+constexpr int kLdsGuard = 512;
 #else
 constexpr int kLdsGuard = 0;
 #endif
@@ -94,7 +94,7 @@ struct IcpArgs {
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
     int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
     int polar_copy = 0;        // set by launch_icp: the kernel carves the unpadded second copy of the target (nn_polar)
-    int team_cap = 0;          // set by launch_icp: first-iteration queries the lane teams can take (nn_team), 0: none
+    int team_cap = 0;          // set by launch_icp: room in the LDS list of first-iteration queries without a beam window (nn_listed), 0: none
     int team_mode = 0;         // context option "icp_team": 0 = on where it applies, 1 = off (the box search takes every such query)
 };
 

@@ -87,8 +87,8 @@ int slam_check_status(slam_ctx *ctx);
  *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
  *   overlap several smaller launches set 3).
  * "icp_team": first-iteration queries of a scan without a usable beam window (range jumps between
- *   the two scans): 0 = searched exhaustively by teams of 16 lanes (default), 1 = by the box
- *   search of the lane that owns them.  Same results; an A/B switch.
+ *   the two scans): 0 = compacted into a list and searched apart from the lanes that own them
+ *   (default), 1 = by the box search of the owning lane.  Same results; an A/B switch.
  * "pipeline": 1 = slam_replay_dev with a map runs as three stages on three streams of the
  *   context (scan matching | pose composition | slam_grid_reset -> ray cast ->
  *   slam_grid_finalize_dev), so the map stage of one replay overlaps the scan matching of the
