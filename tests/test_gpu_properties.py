@@ -237,3 +237,38 @@ def test_replay_scan_matching_random_scans(slam, syn, seed, n, scans, points, ki
     oposes, oT, oit, _ = checks.replay_reference(r, amin, amax, None, points, 30, 1e-3, threads=4)
     assert np.array_equal(it, oit), (it, oit)
     assert np.max(np.abs(T - oT.reshape(T.shape))) < 1e-8
+
+
+def test_scan_matcher_random_streams_both_first_iteration_paths(slam):
+    """Seeded random scan streams - room replays at several strides, range jumps in a third of the beams, quantised ranges
+    with inf beams, surfaces-free random ranges; 2 to 1 500 beams - through the fused replay with the first iteration's
+    window-less queries listed (icp_team 0) and with the box search (1): bit-identical between the two, iteration counts
+    equal to the oracle's and poses to 1e-9.  (A 1 000-case run of the same generator passed when the listed path was
+    written; SLAM_HYP_EXAMPLES scales this one.)"""
+    AMIN, AMAX = -3.14159, 3.14159
+    rng = np.random.default_rng(5)
+    for case in range(max(40, int(os.environ.get("SLAM_HYP_EXAMPLES", "60")) // 2)):
+        n = int(rng.choice([2, 3, 5, 17, 63, 64, 65, 120, 191, 192, 193, 360, 361, 500, 777, 1080, 1500]))
+        kind = int(rng.integers(0, 5))
+        if kind <= 2:
+            ranges = slam.synthetic.make_replay(5, n, seed=int(rng.integers(1, 1000)), stride=int(rng.choice([1, 5, 12])),
+                                                room_scale=float(rng.choice([1.0, 2.0]))).ranges.copy()
+        else:
+            ranges = rng.uniform(0.2, 20.0, size=(5, n)).astype(np.float32)
+        if kind == 1:
+            m = rng.random(ranges.shape) < 0.3
+            ranges[m] = rng.uniform(0.3, 25.0, size=int(m.sum())).astype(np.float32)
+        if kind == 2:
+            ranges = (np.round(ranges * 20) / 20).astype(np.float32)
+            ranges[rng.random(ranges.shape) < 0.05] = np.inf
+        out = []
+        for team in (0, 1):
+            ctx = slam.Context(0)
+            ctx.set_option("icp_team", team)
+            out.append(slam.replay_host(ranges, AMIN, AMAX, context=ctx))
+            ctx.close()
+        (p0, T0, it0), (p1, T1, it1) = out
+        oposes, oT, oit, _ = co.replay(ranges, AMIN, AMAX, None, threads=8)
+        assert np.array_equal(it0, it1) and np.array_equal(T0, T1), (case, n, kind)
+        assert np.array_equal(it0, oit), (case, n, kind)
+        assert np.nanmax(np.abs(p0 - oposes)) < FTOL, (case, n, kind)
