@@ -805,7 +805,7 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // ---------------------------------------------------------------------------------
 // k_icp: ICP.process (icp.py:38-88), one workgroup per pair, QPT queries per lane.
 // ---------------------------------------------------------------------------------
-constexpr int kIcpExtraLds = 32;               // polar_probe words, count of listed queries, re-do flag
+constexpr int kIcpExtraLds = 32;               // flag words: source set collapsed, count of listed queries, re-do
 __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
 // cross-wave stage of the reductions ([2][nwaves][9] doubles: the nine values of the one-pass iteration; 144 B a wave, so
 // what follows stays 16-byte aligned) and of the collapsed-set test ([2][nwaves][4]: matched point of the wave's first
@@ -832,7 +832,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + p_bytes);             // [2][nwaves][kRedStride]
     double *cref = red + 2 * nwaves * kRedStride;                                                // [2][nwaves][4]
-    unsigned *geo = reinterpret_cast<unsigned *>(cref + 2 * nwaves * 4);                          // [8] polar_probe; geo[3]: source set collapsed; geo[4]: queries listed for the teams; geo[5]: re-do flag
+    unsigned *geo = reinterpret_cast<unsigned *>(cref + 2 * nwaves * 4);                          // [8] flags: [3] source set collapsed, [4] queries listed for nn_listed, [5] re-do (the others unused)
     double2 *qlist = reinterpret_cast<double2 *>(geo + 8);                                      // [a.team_cap] nn_listed
     int *qseed = reinterpret_cast<int *>(qlist + a.team_cap);                                    // [a.team_cap]
     char *guard = reinterpret_cast<char *>(qseed + a.team_cap);
@@ -917,8 +917,8 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     double pre_error = 0.0, mean_error = 0.0, pcx = 0.0, pcy = 0.0;
     int iters = 0, par = 0;
     bool amb_any = false;
-    // one iteration; FIRST: the instance for iteration 0 (the only one that lists queries for the lane teams, and the
-    // loop behind it stays the code it was); returns true when the solve has converged (icp.py:76-77)
+    // one iteration; FIRST: the instance for iteration 0 (two reductions as the reference; the only one that lists queries
+    // for nn_listed), the loop behind it takes the one-pass form; returns true when the solve has converged (icp.py:76-77)
     auto iterate = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
         constexpr bool FIRST = decltype(first_tag)::value;
         double mx[QPT], my[QPT], dq[QPT];

@@ -16,8 +16,8 @@ namespace slam {
 // slam_abi.hip), every launch inside it asks the bracket for a fresh pair of events and carries
 // them as the dispatch's own start / stop events (hipExtLaunchKernelGGL), so they bracket exactly
 // the kernel's execution - what rocprofv3's kernel trace reports - and no marker packets are put
-// into the queue.  A family that is several launches (the scan matcher's re-do launch, the byte-
-// window ray cast and its fallback) is the sum of its launches.
+// into the queue.  A family that is several launches (the byte-window ray cast and its fallback,
+// the wedge sort and cast) is the sum of its launches.
 struct LaunchTimer {
     void *self;
     bool (*next)(void *self, hipEvent_t *e0, hipEvent_t *e1);
