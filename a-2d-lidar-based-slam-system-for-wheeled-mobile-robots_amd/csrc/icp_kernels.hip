@@ -434,11 +434,7 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // Queries whose window is wide (no good match: newly visible surfaces) or whose bound does not
 // apply (closer to the origin than 2 sqrt(U), NaN) are left to the box search (`big`).
 // ---------------------------------------------------------------------------------
-constexpr int kPolarMax = 32;     // widest window (beams) the polar search takes ...
-// ... in the launch shape that re-guesses useless first guesses (PROBE); the shapes without take windows four times
-// as wide before they ask the box search: what bounds a lone launch is its first iteration, where 14 % of the
-// lanes have wide windows (999 pairs alone 0.128 -> 0.118 ms with 72 and more; no gain for the PROBE shape)
-constexpr int kPolarMaxLone = 96;
+constexpr int kPolarMax = 96;                 // widest window (beams) a lane searches itself before it asks the box search ...
 constexpr int kPolarMaxFirst = 16;            // ... and in a first iteration whose wider ones are listed (nn_listed: 16 / 24 / 32 within 1 %),
 constexpr int kPolarMaxListed = 48;           // where a window may be this wide after the re-guess
 constexpr int kPolarProbe = 8;                // beams either side of a useless guess that are tried for a better one
@@ -456,8 +452,8 @@ struct PolarGeo {
 
 template <int UNROLL, bool PROBE>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
-                                         bool active, const PolarGeo &geo, int wmax, bool probe, double &best_d2,
-                                         int &best_j, bool &big, bool &amb)
+                                         bool active, const PolarGeo &geo, int wmax, double &best_d2, int &best_j, bool &big,
+                                         bool &amb)
 {
     seed = min(max(seed, 0), n_tar - 1);
     const float fsx = (float)sx, fsy = (float)sy;
@@ -526,11 +522,10 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         }
     };
     bool fits = window(seed, lo, hi);
-    // (PROBE: in the launch shape for a full chip - three queries per lane - where it saves instructions:
-    // 10 000 pairs 0.425 -> 0.395 ms.  A lone 999-pair launch with two queries per lane is bound by the latency
-    // of its longest solves and got SLOWER with it, 0.116 -> 0.128 ms, although its first iteration got shorter:
-    // a workgroup waits for its slowest wave, and 65 % of the pairs still have one that needs the box search.)
-    if (PROBE && probe && __any(active && !fits)) {
+    // (PROBE: for the listed queries of a first iteration, nn_listed.  Until the end of round 3 the lanes of the
+    // three-queries launch shape re-guessed for themselves, in every iteration; with the first iteration's
+    // window-less queries listed, that shape is 16 % shorter without it when replays overlap: 0.183 against 0.218 ms.)
+    if (PROBE && __any(active && !fits)) {
         // A guess that bounds nothing useful - before the first update source and target point of one beam
         // lie on ONE ray, and where the two scans see different surfaces there (14 % of the lanes, in 84 %
         // of the wave-queries) the bound is the range jump - is replaced by the best of the 17 beams around
@@ -637,7 +632,7 @@ __device__ __forceinline__ void nn_listed(const double2 *__restrict__ tarP, int 
         double d2;
         int j;
         bool big, amb;
-        nn_polar<UNROLL, true>(tarP, n_tar, qp.x, qp.y, qseed[act ? e : nq - 1], act, geo, kPolarMaxListed, true, d2, j, big, amb);
+        nn_polar<UNROLL, true>(tarP, n_tar, qp.x, qp.y, qseed[act ? e : nq - 1], act, geo, kPolarMaxListed, d2, j, big, amb);
         if (act && !big) qlist[e] = make_double2(d2, __hiloint2double(0, j | (amb ? (int)0x80000000 : 0)));
         unsigned long long left = __ballot(big);
         while (left != 0ull) {                                       // four of the remaining queries, one per row
@@ -816,7 +811,7 @@ __host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 *
 // EXACT: the second pass over a pair in which the first saw a best undercut its predecessor by less than a class of
 // equal distances (see "Best"): the same solve with the reference's own nearest-neighbour loop (nn_exact).
 // Returns whether the pair needs that second pass (the same value in every lane; false from the second pass).
-template <typename T, int QPT, int UNROLL, bool PROBE, bool EXACT>
+template <typename T, int QPT, int UNROLL, bool EXACT>
 __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *smem)
 {
     ISTAMP_DECL;
@@ -935,8 +930,8 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
                 d2 = h.d2; j = h.j;
             } else if (pg.inv_db > 0.0f) {                           // wave-uniform: the target is a scan
                 bool big;
-                nn_polar<UNROLL, PROBE>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg,
-                                        team_it ? kPolarMaxFirst : (PROBE ? kPolarMax : kPolarMaxLone), !team_it, d2, j, big, amb);          // icp.py:67
+                nn_polar<UNROLL, false>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, team_it ? kPolarMaxFirst : kPolarMax, d2, j,
+                                        big, amb);                   // icp.py:67
                 if (FIRST && team_it) {
                     const unsigned long long bm = __ballot(big);
                     if (bm != 0ull) {
@@ -1141,13 +1136,13 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
 // need the second pass (icp_pair<EXACT>); the workgroup of such a pair runs it right away - until round 3 a
 // second launch did, which cost every batch 4 us whether or not a pair was flagged.  The second pass overwrites
 // the outputs of the first.  (Registers are the larger of the two passes' needs, not their sum.)
-template <typename T, int QPT, int UNROLL, bool PROBE>
+template <typename T, int QPT, int UNROLL>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (icp_pair<T, QPT, UNROLL, PROBE, false>(a, blockIdx.x, smem)) {
+    if (icp_pair<T, QPT, UNROLL, false>(a, blockIdx.x, smem)) {
         __syncthreads();                                             // the second pass re-uses the LDS
-        icp_pair<T, QPT, 2, false, true>(a, blockIdx.x, smem);
+        icp_pair<T, QPT, 2, true>(a, blockIdx.x, smem);
     }
 }
 
@@ -1190,26 +1185,26 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     lds += (size_t)a.team_cap * (sizeof(double2) + sizeof(int));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.B);
-#define SLAM_ICP_CASE(Q, U, P)                                                                                  \
+#define SLAM_ICP_CASE(Q, U)                                                                                     \
     {                                                                                                           \
         if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U, P>),                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_icp<T, Q, U>),                         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        SLAM_LAUNCH((k_icp<T, Q, U, P>), grid, dim3(block), lds, s, a);                                         \
+        SLAM_LAUNCH((k_icp<T, Q, U>), grid, dim3(block), lds, s, a);                                            \
     }
     // (one wave per pair with six queries per lane - no barriers, the per-iteration fixed work paid
     // once per pair - was measured: 12 % fewer instructions, but 0.28 instead of 0.20 ms alone and
     // no faster with replays overlapping: dropped)
-    // (candidates per trip of the beam-window search and the re-guess of useless first guesses: see nn_polar.  Four
+    // (candidates per trip of the beam-window search: see nn_polar.  Four
     // per trip are as fast as two when the chip is full and faster when it is not - four overlapping 999-pair
     // replays 8.5 -> 8.9 M scans/s - since the candidates come from the unpadded copy.)
-    if (qpt <= 1) SLAM_ICP_CASE(1, 4, false)
-    else if (qpt <= 2) SLAM_ICP_CASE(2, 4, false)
-    else if (qpt <= 3) SLAM_ICP_CASE(3, 4, true)
-    else if (qpt <= 4) SLAM_ICP_CASE(4, 2, true)
-    else if (qpt <= 8) SLAM_ICP_CASE(8, 2, true)
+    if (qpt <= 1) SLAM_ICP_CASE(1, 4)
+    else if (qpt <= 2) SLAM_ICP_CASE(2, 4)
+    else if (qpt <= 3) SLAM_ICP_CASE(3, 4)
+    else if (qpt <= 4) SLAM_ICP_CASE(4, 2)
+    else if (qpt <= 8) SLAM_ICP_CASE(8, 2)
     else return hipErrorInvalidValue;   // n_src > 8192
 #undef SLAM_ICP_CASE
     return hipGetLastError();

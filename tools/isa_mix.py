@@ -22,7 +22,7 @@ def main():
                                "-I" + CSRC, "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "icp_kernels.hip")], stderr=subprocess.DEVNULL)
         text = open(asm).read()
     out = {}
-    for name, sym in (("qpt2", "_ZN4slam5k_icpIdLi2ELi4ELb0EEEvNS_7IcpArgsE"), ("qpt3", "_ZN4slam5k_icpIdLi3ELi4ELb1EEEvNS_7IcpArgsE")):
+    for name, sym in (("qpt2", "_ZN4slam5k_icpIdLi2ELi4EEEvNS_7IcpArgsE"), ("qpt3", "_ZN4slam5k_icpIdLi3ELi4EEEvNS_7IcpArgsE")):
         m = re.search(r"^%s:.*?^\s*\.amdhsa_kernel %s" % (re.escape(sym), re.escape(sym)), text, re.S | re.M)
         body = m.group(0) if m else ""
         valu = re.findall(r"^\s+(v_\w+)", body, re.M)
@@ -32,7 +32,7 @@ def main():
         out[name] = {"valu": len(valu), "f64": len(f64)}
     tot = out["qpt2"]
     res = {"f64_share": tot["f64"] / float(max(tot["valu"], 1)), "static_valu_instructions": tot["valu"], "static_f64_instructions": tot["f64"],
-           "kernel": "k_icp<double, 2, 4, false> (both passes, every search path)", "qpt3": out["qpt3"],
+           "kernel": "k_icp<double, 2, 4> (both passes, every search path)", "qpt3": out["qpt3"],
            "note": "static count over the kernel's ISA (hipcc -S); f64 = mnemonics with an f64 operand type (4 issue cycles), the rest 2"}
     json.dump(res, open(sys.argv[1], "w"), indent=1)
     print(res)
