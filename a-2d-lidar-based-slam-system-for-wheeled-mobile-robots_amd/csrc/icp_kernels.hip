@@ -1140,6 +1140,14 @@ template <typename T, int QPT, int UNROLL>
 __global__ void __launch_bounds__(1024) k_icp(IcpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.zero_ptr) {
+        // the replay's map counters, cleared on the way (16 bytes a lane, fire and forget) instead of by a fill kernel of
+        // its own ahead of this launch: one dispatch less on the replay's stream
+        uint4 *p = static_cast<uint4 *>(a.zero_ptr);
+        const size_t n16 = a.zero_bytes >> 4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0 && threadIdx.x < ((a.zero_bytes & 15) >> 2)) static_cast<unsigned *>(a.zero_ptr)[(n16 << 2) + threadIdx.x] = 0u;
+    }
     if (icp_pair<T, QPT, UNROLL, false>(a, blockIdx.x, smem)) {
         __syncthreads();                                             // the second pass re-uses the LDS
         icp_pair<T, QPT, 2, true>(a, blockIdx.x, smem);
@@ -1367,8 +1375,12 @@ hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const
 // walked by one lane, in the reference's evaluation order:
 //   x = (x + cos(th)*tx) - sin(th)*ty;  y = (y + sin(th)*tx) + cos(th)*ty;  th = th + dyaw.
 // ---------------------------------------------------------------------------------
-constexpr int kComposeChunk = 2048;
-constexpr int kComposeThreads = 1024;
+// A small footprint on purpose (256 lanes, 24 KB of LDS; 1 024 lanes and 96 KB until the end of round 3): the
+// kernel is one workgroup per trajectory that other kernels' workgroups have to make room for - when replays overlap on
+// several contexts its launch waited for a CU with that much free LDS, 57 us instead of 27 from dispatch to end, and
+// its stream stood still meanwhile (four overlapping 999-pair replays: 9.2 -> 10.0 M scans/s with the small one).
+constexpr int kComposeChunk = 512;
+constexpr int kComposeThreads = 256;
 constexpr int kComposeUnroll = 16;
 
 // The two serial scans are latency chains of float64 adds.  One lane walks the heading
@@ -1381,6 +1393,8 @@ __global__ void __launch_bounds__(kComposeThreads) k_pose_compose(const double *
     __shared__ double dyaw[kComposeChunk], thb[kComposeChunk];
     __shared__ double add1[2][kComposeChunk], sub2[2][kComposeChunk];   // [0]: x terms, [1]: y terms
     __shared__ double carry[3];
+    // (a latency chain on one wave: on a SIMD shared with other kernels' waves it would get every fourth issue slot)
+    __builtin_amdgcn_s_setprio(3);
     const int l = blockIdx.x, tid = threadIdx.x;
     const double *Tl = T + 9 * (long)l * n;
     double *Pl = poses + 3 * (long)l * n;

@@ -87,6 +87,7 @@ struct slam_ctx {
     int grid_group = 0;   // scans per workgroup in window mode (0: automatic)
     int grid_split = -1;  // window mode: two workgroups per group, one per direction half (-1: when the launch cannot fill the chip)
     int icp_qpt = 0;      // queries per lane of batched scan matching (0: by batch size)
+    int replay_reset = 0; // 1: slam_replay_dev clears its map's counters itself (inside the scan-matching launch)
     int icp_team = 0;     // first-iteration queries without a beam window: 0 = listed and searched apart from their lanes (nn_listed), 1 = box search
     // "pipeline" option: the map stage of slam_replay_dev (reset -> ray cast -> finalize) runs on
     // a second stream, so the map stage of one replay overlaps the scan matching of the next.
@@ -446,6 +447,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     if (!strcmp(name, "grid_mode")) { REQUIRE(value == 0 || value == 1 || value == 2 || value == 3 || value == 4, "grid_mode is 0..4"); c->grid_mode = (int)value; }
     else if (!strcmp(name, "grid_group")) { REQUIRE(value >= 0 && value <= 64, "grid_group in [0, 64]"); c->grid_group = (int)value; }
     else if (!strcmp(name, "grid_split")) { REQUIRE(value == -1 || value == 0 || value == 1, "grid_split is -1, 0 or 1"); c->grid_split = (int)value; }
+    else if (!strcmp(name, "replay_reset")) { REQUIRE(value == 0 || value == 1, "replay_reset is 0 or 1"); c->replay_reset = (int)value; }
     else if (!strcmp(name, "icp_team")) { REQUIRE(value == 0 || value == 1, "icp_team is 0 or 1"); c->icp_team = (int)value; }
     else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
@@ -1107,6 +1109,17 @@ int slam_replay_dev(slam_ctx *c, const float *ranges, const double *cos_t, const
         a.B = (int)pairs; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
         a.T_out = T; a.iters_out = iters_out; a.err_out = nullptr;
         a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
+        if (grid && c->replay_reset) {
+            // option "replay_reset": the map starts from zero for this replay.  On one stream the scan-matching launch
+            // clears the counters on its way (they are next touched by the ray cast behind it); maps with a live pmap and
+            // the three-stream pipeline go through slam_grid_reset.
+            if (piped || grid->pmap_live) {
+                TRY(slam_grid_reset(c, grid));
+            } else {
+                a.zero_ptr = grid->d.pass; a.zero_bytes = grid->state_bytes;
+                grid->pristine = true;
+            }
+        }
         Timed t(c, SLAM_K_ICP);
         HIPCHK(launch_icp(a, dtype, c->stream));
     }

@@ -93,6 +93,8 @@ struct IcpArgs {
     double *err_out;           // nullable [B]
     int *status = nullptr;     // sticky status word of the context (LDS guard builds)
     int qpt_pref = 0;          // queries per lane in batched launches: 0 = by batch size (context option "icp_qpt")
+    void *zero_ptr = nullptr;  // nullable: zero_bytes bytes (a multiple of 4, 16-byte aligned start) that the launch clears on its way -
+    size_t zero_bytes = 0;     //   the counters of the map the replay's ray cast fills next (slam_replay_dev, option "replay_reset")
     int polar_copy = 0;        // set by launch_icp: the kernel carves the unpadded second copy of the target (nn_polar)
     int team_cap = 0;          // set by launch_icp: room in the LDS list of first-iteration queries without a beam window (nn_listed), 0: none
     int team_mode = 0;         // context option "icp_team": 0 = on where it applies, 1 = off (the box search takes every such query)

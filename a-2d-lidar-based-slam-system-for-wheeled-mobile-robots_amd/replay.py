@@ -227,6 +227,7 @@ class DeviceReplay:
         if grid_of_traj is not None:
             self.got = torch.from_numpy(np.ascontiguousarray(np.asarray(grid_of_traj, dtype=np.int32))).to(self.dev)
         self.max_iter, self.tol = int(max_iter), float(tolerance)
+        self._reset_opt = 0
         torch.cuda.synchronize(self.dev)
 
     def make_grid(self, G, xw, yw, reso, **kw):
@@ -245,8 +246,11 @@ class DeviceReplay:
                 if tuple(buf.shape) != tuple(cur.shape) or buf.dtype != cur.dtype or not buf.is_contiguous():
                     raise ValueError("%s_out must be a contiguous float64 tensor of shape %r" % (name, tuple(cur.shape)))
                 setattr(self, name, buf)
-        if self.grid is not None and reset_grid:
-            self.grid.reset()
+        if self.grid is not None:          # (the reset rides on the scan-matching launch: context option "replay_reset")
+            want = 1 if reset_grid else 0
+            if want != self._reset_opt:
+                self.ctx.set_option("replay_reset", want)
+                self._reset_opt = want
         _abi.check(_abi.lib().slam_replay_dev(
             self.ctx.handle, self.ranges.data_ptr(), self.cos_t.data_ptr(), self.sin_t.data_ptr(), self.L, self.n_scan,
             self.n, self.code, self.max_iter, self.tol, self.pose0.data_ptr(),

@@ -86,6 +86,9 @@ int slam_check_status(slam_ctx *ctx);
  * "icp_qpt": queries per lane of batched scan matching, 1..3; 0 = by batch size (two for
  *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
  *   overlap several smaller launches set 3).
+ * "replay_reset": 1 = slam_replay_dev starts its map from zero (as slam_grid_reset before it would),
+ *   clearing the counters inside its scan-matching launch: one dispatch less per replay.  0
+ *   (default): the map accumulates across replays until slam_grid_reset.
  * "icp_team": first-iteration queries of a scan without a usable beam window (range jumps between
  *   the two scans): 0 = compacted into a list and searched apart from the lanes that own them
  *   (default), 1 = by the box search of the owning lane.  Same results; an A/B switch.

@@ -63,7 +63,7 @@ def test_config4_dense_1080_f16_2000x2000_tiles(slam, syn):
 # ------------------------------------------------------------------ configs[3] per-GPU share
 def test_config3_share_5000_scan_replay(slam, syn):
     """One rank's share of BASELINE configs[3]: a 5 000-scan trajectory (seed 10 = rank 0's),
-    360 beams, 400x400 @ 0.05 m.  4 999 transforms cross the 2 048-step chunk of the pose
+    360 beams, 400x400 @ 0.05 m.  4 999 transforms cross the 512-step chunks of the pose
     composition kernel twice."""
     rep = syn.make_replay(5000, 360, seed=10, stride=5)
     _, grid, dev = _device_replay(slam, rep, "f64", 400, 400, 0.05)
