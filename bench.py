@@ -67,7 +67,7 @@ AMIN, AMAX = -3.14159, 3.14159
 CONFIGS = {
     # name: scans, beams, grid, reso, room_scale, points, seed, lanes
     "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=4),
-    "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=3),
+    "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=4),
     "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=2),
 }
 
