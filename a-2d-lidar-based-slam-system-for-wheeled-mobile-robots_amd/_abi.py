@@ -191,8 +191,12 @@ class Context:
     def set_option(self, name, value):
         check(lib().slam_set_option(self.handle, name.encode(), float(value)))
 
-    def timing_enable(self, on=True):
-        check(lib().slam_timing_enable(self.handle, int(bool(on))))
+    def timing_enable(self, on=True, only=None):
+        """``only``: family names (K_NAMES) whose launches carry events; None: every family."""
+        code = int(bool(on))
+        if on and only is not None:
+            code = 2 * sum(1 << K_NAMES.index(k) for k in only)
+        check(lib().slam_timing_enable(self.handle, code))
 
     def timing_read(self):
         """{family: (milliseconds, launches)} since the last read."""

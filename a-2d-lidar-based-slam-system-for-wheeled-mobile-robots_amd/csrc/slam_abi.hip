@@ -79,6 +79,7 @@ struct slam_ctx {
     size_t pinned_cap = 0;
     int *status = nullptr;
     bool timing = false;
+    unsigned timing_mask = ~0u;   // families (bit SLAM_K_*) whose launches carry events while timing is on
     std::vector<hipEvent_t> pool;
     std::vector<Pending> pending;
     double ms[SLAM_K_COUNT] = {0};
@@ -177,7 +178,7 @@ struct Timed {
     bool used = false;
     Timed(slam_ctx *ctx, int k, hipStream_t = nullptr) : c(ctx), kind(k), saved(g_launch_timer)
     {
-        if (c->timing) g_launch_timer = {this, &Timed::next};
+        if (c->timing && (c->timing_mask >> k & 1u)) g_launch_timer = {this, &Timed::next};
     }
     ~Timed() { g_launch_timer = saved; }
     static bool next(void *self, hipEvent_t *e0, hipEvent_t *e1)
@@ -477,6 +478,7 @@ int slam_timing_enable(slam_ctx *c, int on)
     c->pending.clear();
     for (int k = 0; k < SLAM_K_COUNT; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
     c->timing = on != 0;
+    c->timing_mask = on > 1 ? (unsigned)on >> 1 : ~0u;   // on = 1: every family; on = 2 * mask: the families in mask (bit SLAM_K_*)
     return SLAM_OK;
 }
 

@@ -101,7 +101,9 @@ int slam_check_status(slam_ctx *ctx);
  *   on this context.  0 = everything on the context's stream (default). */
 int slam_set_option(slam_ctx *ctx, const char *name, double value);
 /* Per-kernel-family timing with HIP events on the context's stream (bench.py roofline).
- * read: synchronises, adds up elapsed ms and launch counts since the last reset. */
+ * on: 0 = off, 1 = every family, 2 * mask = only the families in mask (bit SLAM_K_*): events on a
+ * dispatch cost throughput (3-4 % with four replays overlapping), a caller that needs one family's
+ * times pays for one.  read: synchronises, adds up elapsed ms and launch counts since the last reset. */
 int slam_timing_enable(slam_ctx *ctx, int on);
 int slam_timing_read(slam_ctx *ctx, double ms_out[SLAM_K_COUNT], int64_t launches_out[SLAM_K_COUNT]);
 
