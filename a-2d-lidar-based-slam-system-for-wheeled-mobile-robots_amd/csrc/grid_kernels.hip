@@ -1388,6 +1388,17 @@ __device__ __forceinline__ void lds_or_u32(unsigned addr, unsigned v)
     (void)__hip_atomic_fetch_or((lds_u32_t *)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// New value of a quad's four pmap bytes (mapping.py:47-50) from their old value and what the scan did to the cells (one bit
+// per byte - 7: touched, 6: hit, 5: pass count at or over the threshold now): a touched cell shows 100 if it was occupied
+// (bit 6 is set in 100 only, not in 0 or 50), is hit now or is over the threshold, else 0; an untouched cell keeps its byte.
+__device__ __forceinline__ uint32_t own8_pmap_bytes(uint32_t o, uint32_t e)
+{
+    const uint32_t tb = (e >> 7) & 0x01010101u;
+    const uint32_t occ = ((o >> 6) | (e >> 6) | (e >> 5)) & 0x01010101u;
+    const uint32_t tm = tb * 255u;
+    return (o & ~tm) | ((occ * 100u) & tm);
+}
+
 template <class Src, int THREADS, int BATCH>
 __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k_grid_update_owner8(GridDev g, Src src, int win_bytes, int32_t *__restrict__ redo)
 {
@@ -1563,27 +1574,45 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
         const bool org_lane = c == org_q;
         for (int r0 = wv; r0 < W; r0 += NW * BATCH) {
             u32x4_t p[BATCH];
-            uint32_t om[BATCH], dd[BATCH], vo[BATCH];
+            uint32_t om[BATCH], dd[BATCH], vo[BATCH], vp[BATCH], ev[BATCH];
+            auto rowoff_of = [&](int u) -> uint32_t {                // (wave-uniform) first cell of the segment in map row x0 + r
+                const int rc = min(r0 + u * NW, W - 1);
+                return (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
+            };
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int r = r0 + u * NW;                           // (wave-uniform)
                 const int rc = min(r, W - 1);
-                const uint32_t rowoff = (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
                 dd[u] = (incol && r < W) ? win[rc * qrow + c] : 0u;
                 // the four lanes of a piece decide together (rows start on a piece, 64 lanes are 16 pieces)
                 const unsigned long long m = __ballot(dd[u] != 0u || (r == org_r && org_lane));
                 const bool live = ((m >> (lane & 60)) & 0xFull) != 0ull && incol;
                 vo[u] = live ? (unsigned)lane << 4 : kSkip;         // byte offset of the lane's quad in the counter row
-                p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff << 2, kOwn8Aux);
-                om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vo[u] >> 2, rowoff, kOwn8Aux);
+                p[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_pass, vo[u], rowoff_of(u) << 2, kOwn8Aux);
             }
+            // pmap (mapping.py:47-50).  A touched cell shows 0 or 100 afterwards; its byte CHANGES only if the cell was never
+            // touched before (then its old pass count is 0), or is hit now and was not occupied, or its pass count is at or
+            // over the threshold now.  The old bytes are read where they can matter.  Up front: quads a hit fell in.  The
+            // other two cases are known once the counters are here and are rare once a map has seen a scan or two: those
+            // quads read pmap late (below).  The up-front reads are issued BEHIND the batch's counter loads: a wave's loads
+            // return in order, and a lone lane's pmap line coming from memory between two rows' counters held every later
+            // row of the batch back.  (Per 10 000 maps: pmap read for every live quad, as until round 3, 0.671 ms and
+            // 3.20 GB; for the quads that need it, each between its row's counters and the next row's, 0.722 ms; behind the
+            // counter loads 0.640 ms and 2.94 GB; listed in LDS and settled after the sweep in one round 0.718 ms - that
+            // round trip is paid at the end of every workgroup's life, with nothing left to overlap it.)
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                vp[u] = (vo[u] != kSkip && (dd[u] & 0x80808080u) != 0u) ? (unsigned)lane << 2 : kSkip;
+                om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, vp[u], rowoff_of(u), kOwn8Aux);
+            }
+            bool late_any = false;
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int r = r0 + u * NW;
-                const int rc = min(r, W - 1);
-                const uint32_t rowoff = (uint32_t)((x0 + rc) * g.yw + y4 + seg * 4 * kWave);
                 const uint32_t d = dd[u], dm = d & 0x7f7f7f7fu;
                 u32x4_t q = p[u];
+                // one bit per cell (bit 7 of its byte): its pass count was 0 before this scan
+                const uint32_t z7 = (q.x == 0u ? 0x80u : 0u) | (q.y == 0u ? 0x8000u : 0u) | (q.z == 0u ? 0x800000u : 0u) | (q.w == 0u ? 0x80000000u : 0u);
                 q.x += dm & 0xffu; q.y += (dm >> 8) & 0xffu; q.z += (dm >> 16) & 0xffu; q.w += dm >> 24;   // mapping.py:43
                 // one bit per cell (bit 7 of its byte): passed or hit by this scan
                 uint32_t t7 = ((dm + 0x7f7f7f7fu) | d) & 0x80808080u;
@@ -1594,20 +1623,30 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
                         t7 |= 0x80u << (8u * org_b);
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(q, rs_pass, vo[u], rowoff << 2, kOwn8Aux);
-                // pmap (mapping.py:47-50): a touched cell shows 0 or 100 afterwards.  Its byte changes iff it was never
-                // touched before (50: bit 4 is set in 50 only), or it is hit now and was not occupied (bit 6 is set in
-                // 100 only), or its pass count is at or over the threshold now
-                const uint32_t o = om[u];
-                const uint32_t need = ((t7 >> 3) & o & 0x10101010u) | (d & ~(o << 1) & 0x80808080u);
-                const uint32_t pmax = max(max(q.x, q.y), max(q.z, q.w));
-                if ((need != 0u || pmax >= pthr) && vo[u] != kSkip) {
-                    const uint32_t tb = t7 >> 7, fb = (d >> 7) & 0x01010101u, was = (o >> 6) & 0x01010101u;
-                    uint32_t occ = was | fb;
-                    occ |= (q.x >= pthr ? 1u : 0u) | (q.y >= pthr ? 0x100u : 0u) | (q.z >= pthr ? 0x10000u : 0u) | (q.w >= pthr ? 0x1000000u : 0u);
-                    const uint32_t tm = tb * 255u;
-                    const uint32_t out = (o & ~tm) | ((occ * 100u) & tm);
-                    if (out != o) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vo[u] >> 2, rowoff, kOwn8Aux);
+                __builtin_amdgcn_raw_buffer_store_b128(q, rs_pass, vo[u], rowoff_of(u) << 2, kOwn8Aux);
+                // what the scan did to the quad's cells, one bit per byte - 7: touched, 6: hit, 5: count at or over the threshold
+                const uint32_t ge5 = (q.x >= pthr ? 0x20u : 0u) | (q.y >= pthr ? 0x2000u : 0u) | (q.z >= pthr ? 0x200000u : 0u) | (q.w >= pthr ? 0x20000000u : 0u);
+                ev[u] = t7 | ((d >> 1) & 0x40404040u) | ge5;
+                if (vp[u] == kSkip && vo[u] != kSkip && ((t7 & z7) != 0u || (ge5 & (t7 >> 2)) != 0u)) {
+                    vp[u] = ((unsigned)lane << 2) | 1u;              // (bit 0: read late)
+                    late_any = true;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {                        // the quads read up front
+                if (vp[u] == kSkip || (vp[u] & 1u)) continue;
+                const uint32_t out = own8_pmap_bytes(om[u], ev[u]);
+                if (out != om[u]) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vp[u], rowoff_of(u), kOwn8Aux);
+            }
+            if (__any(late_any)) {
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u)
+                    om[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_pm, (vp[u] != kSkip && (vp[u] & 1u)) ? vp[u] & ~3u : kSkip, rowoff_of(u), kOwn8Aux);
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    if (vp[u] == kSkip || !(vp[u] & 1u)) continue;
+                    const uint32_t out = own8_pmap_bytes(om[u], ev[u]);
+                    if (out != om[u]) __builtin_amdgcn_raw_buffer_store_b32(out, rs_pm, vp[u] & ~3u, rowoff_of(u), kOwn8Aux);
                 }
             }
         }
@@ -2023,7 +2062,7 @@ size_t tile_scratch_bytes(long rays, long groups)
 bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj)
 {
     // one shared map, much larger than a window; a group's ray count must fit the 16-bit tile counters
-    return !got && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= 8192;
+    return !got && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= kTileMaxBeams;
 }
 
 template <class Src>
@@ -2035,6 +2074,7 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
     int G = group > 0 ? group : 16;
     G = std::min(G, std::max(1, 65535 / n));
     G = std::min(G, scans);
+    if ((long)G * n > 65535) return hipErrorInvalidValue;   // (the tile counters and a group's ray numbers are 16-bit)
     if (L > 1)                                    // a group is a contiguous range of ray ids: it must not straddle streams
         while (scans % G != 0) --G;
     const int groups_per_traj = (scans + G - 1) / G;
@@ -2430,6 +2470,7 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     int G = group > 0 ? group : 16;
     G = std::min(G, std::max(1, 65535 / n));
     G = std::min(G, scans);
+    if ((long)G * n > 65535) return hipErrorInvalidValue;   // (ray numbers inside a group are 16-bit: keys[], ws.list[])
     const int groups_per_traj = (scans + G - 1) / G;
     const long groups = (long)L * groups_per_traj, rays = (long)L * scans * n;
     if (groups > 65535 || g.xw > 65535 || g.yw > 65535) return hipErrorInvalidValue;   // (end cells travel as 16-bit pairs)

@@ -1493,7 +1493,9 @@ __global__ void __launch_bounds__(256) k_pose_step(const double *__restrict__ T,
 hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
                                const double *prior, double *heading_cs)
 {
-    if (prior || (n == 1 && L > 64)) {
+    // (heading_cs is written by k_pose_step only: a caller that asks for it - the particle pipeline's ray cast reads it -
+    // takes that kernel whatever the batch size and whether or not there are priors)
+    if (prior || heading_cs || (n == 1 && L > 64)) {
         if (n != 1) return hipErrorInvalidValue;
         SLAM_LAUNCH(k_pose_step, dim3((L + 255) / 256), dim3(256), 0, s, T, pose0, prior, L, poses, heading_cs);
         return hipGetLastError();

@@ -104,6 +104,16 @@ struct slam_ctx {
     int cast_pos = 0;
     bool gdirty = false;                             // work on gstream the main stream has not waited for
     bool mgrid = false;                              // map work on the main stream gstream has not waited for
+    // Particle batches in chunks (option "particle_chunks"): scan matching and pose steps of chunk k on the main stream,
+    // its ray cast on pstream behind an event - the vector-issue-bound matcher of chunk k + 1 shares the chip with the
+    // memory-bound ray cast of chunk k (slam_particles_dev).
+    int particle_chunks = 0;                         // 0 / 1: off, else the number of chunks
+    hipStream_t pstream = nullptr;
+    std::vector<hipEvent_t> pev_pose, pev_cast;      // per chunk: "poses written" (main -> pstream), "ray cast done" (pstream -> main)
+    hipEvent_t pev_join = nullptr;
+    bool pdirty = false;                             // ray casts on pstream the main stream has not waited for
+    int p_last_P = 0, p_last_chunks = 0;             // shape of the batch whose casts may still be running: the next batch of the
+    const void *p_last_poses = nullptr;              //   same shape waits chunk by chunk, any other joins first
 };
 
 struct slam_grid {
@@ -122,17 +132,23 @@ thread_local LaunchTimer g_launch_timer = {nullptr, nullptr};
 
 hipError_t allow_dynamic_lds(const void *kernel, int bytes)
 {
+    struct Entry { int dev; const void *kernel; int bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<int, const void *>> done;       // (device, kernel) pairs that have the attribute
+    static std::vector<Entry> done;       // largest size the attribute has been set to, per (device, kernel)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    for (const auto &d : done)
-        if (d.first == dev && d.second == kernel) return hipSuccess;
+    Entry *hit = nullptr;
+    for (auto &d : done)
+        if (d.dev == dev && d.kernel == kernel) hit = &d;
+    if (hit && hit->bytes >= bytes) return hipSuccess;
+    // (a kernel whose LDS need depends on the launch - k_wedge_sort: beams x scans per group - asks again with more)
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done.emplace_back(dev, kernel);
-    return e;
+    if (e != hipSuccess) return e;
+    if (hit) hit->bytes = bytes;
+    else done.push_back(Entry{dev, kernel, bytes});
+    return hipSuccess;
 }
 }  // namespace slam
 
@@ -176,7 +192,9 @@ struct Timed {
     int kind;
     LaunchTimer saved;
     bool used = false;
-    Timed(slam_ctx *ctx, int k, hipStream_t = nullptr) : c(ctx), kind(k), saved(g_launch_timer)
+    // counts: the bracket's first launch counts as a launch of its family (false: one more piece of a family whose
+    // launches are counted elsewhere - the later chunks of a particle batch)
+    Timed(slam_ctx *ctx, int k, hipStream_t = nullptr, bool counts = true) : c(ctx), kind(k), saved(g_launch_timer), used(!counts)
     {
         if (c->timing && (c->timing_mask >> k & 1u)) g_launch_timer = {this, &Timed::next};
     }
@@ -232,9 +250,21 @@ int fork_to_grid(slam_ctx *c)
     return SLAM_OK;
 }
 
+// the main stream must see the ray casts of chunked particle batches (pstream) enqueued so far
+int join_particles(slam_ctx *c)
+{
+    if (!c->pdirty) return SLAM_OK;
+    HIPCHK(hipEventRecord(c->pev_join, c->pstream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pev_join, 0));
+    c->pdirty = false;
+    c->p_last_chunks = 0;
+    return SLAM_OK;
+}
+
 // the main stream must see everything enqueued on the map stream so far
 int join_from_grid(slam_ctx *c)
 {
+    if (int rc = join_particles(c)) return rc;
     if (!c->pipeline || !c->gdirty) return SLAM_OK;
     HIPCHK(hipEventRecord(c->ev_join, c->gstream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -318,6 +348,7 @@ int copy_out_sync(slam_ctx *c, std::initializer_list<Seg> segs)
 // entry points that touch a map on the MAIN stream call this first
 int grid_on_main(slam_ctx *c)
 {
+    if (int rc = join_particles(c)) return rc;
     if (!c->pipeline) return SLAM_OK;
     c->mgrid = true;
     return join_from_grid(c);
@@ -405,6 +436,13 @@ int slam_destroy(slam_ctx *c)
     if (!c) return SLAM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->pstream) {
+        (void)hipStreamSynchronize(c->pstream);
+        (void)hipStreamDestroy(c->pstream);
+        for (hipEvent_t e : c->pev_pose) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->pev_cast) (void)hipEventDestroy(e);
+        if (c->pev_join) (void)hipEventDestroy(c->pev_join);
+    }
     if (c->gstream) {
         (void)hipStreamSynchronize(c->cstream);
         (void)hipStreamSynchronize(c->gstream);
@@ -450,6 +488,7 @@ int slam_set_option(slam_ctx *c, const char *name, double value)
     else if (!strcmp(name, "grid_split")) { REQUIRE(value == -1 || value == 0 || value == 1, "grid_split is -1, 0 or 1"); c->grid_split = (int)value; }
     else if (!strcmp(name, "replay_reset")) { REQUIRE(value == 0 || value == 1, "replay_reset is 0 or 1"); c->replay_reset = (int)value; }
     else if (!strcmp(name, "icp_team")) { REQUIRE(value == 0 || value == 1, "icp_team is 0 or 1"); c->icp_team = (int)value; }
+    else if (!strcmp(name, "particle_chunks")) { REQUIRE(value >= 0 && value <= 64 && value == (int)value, "particle_chunks in [0, 64]"); TRY(join_particles(c)); c->particle_chunks = (int)value; }
     else if (!strcmp(name, "icp_qpt")) { REQUIRE(value >= 0 && value <= 3, "icp_qpt in [0, 3]"); c->icp_qpt = (int)value; }
     else if (!strcmp(name, "pipeline")) {
         REQUIRE(value == 0 || value == 1, "pipeline is 0 or 1");
@@ -485,6 +524,7 @@ int slam_timing_enable(slam_ctx *c, int on)
 int slam_timing_read(slam_ctx *c, double ms_out[SLAM_K_COUNT], int64_t launches_out[SLAM_K_COUNT])
 {
     TRY(use(c));
+    TRY(join_from_grid(c));                 // (timed launches on the map / particle streams)
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &p : c->pending) {
         float ms = 0.f;
@@ -756,6 +796,7 @@ int slam_grid_destroy(slam_ctx *c, slam_grid *g)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->gstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamSynchronize(c->gstream); }
+        if (c->pstream) (void)hipStreamSynchronize(c->pstream);
     }
     if (g->pmap_live) (void)hipFree(g->pmap_live);
     if (g->d.redo) (void)hipFree(g->d.redo);
@@ -770,6 +811,7 @@ int slam_grid_reset(slam_ctx *c, slam_grid *g)
 {
     TRY(use(c));
     REQUIRE(g, "null grid");
+    TRY(join_particles(c));
     if (c->pipeline && c->mgrid) {
         TRY(fork_to_grid(c));
         c->mgrid = false;
@@ -793,9 +835,10 @@ int slam_grid_update_dev(slam_ctx *c, slam_grid *g, const double *ox, const doub
     REQUIRE(B > 0 && n > 0, "sizes must be positive");
     g->pristine = false;
     Timed t(c, SLAM_K_GRID);
-    const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || c->grid_mode == 2 || c->grid_mode == 4);
+    // (forced tiles / wedges keep the bound of the automatic choice on the beam count: ray numbers inside a group are 16-bit)
+    const bool tiles_ok = !grid_of_batch && (tiles_apply(g->d, n, nullptr, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && n <= kTileMaxBeams));
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
-        size_t need = tile_scratch_bytes((long)B * n, B);
+        size_t need = wedges_ok(c, g) ? wedge_scratch_bytes((long)B * n, B, B) : tile_scratch_bytes((long)B * n, B);
         if (need > c->tiles.cap) TRY(arena_reserve(c, c->tiles, need));
         HIPCHK(launch_grid_update_tiles_explicit(g->d, ox, oy, cx, cy, B, n, c->grid_group, c->tiles.base, c->stream, wedges_ok(c, g)));
     } else if (c->grid_mode != 0 && !grid_of_batch) {
@@ -834,10 +877,11 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
                        hipStream_t st)
 {
     g->pristine = false;
-    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && !got);
+    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && !got && n <= kTileMaxBeams);
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         long rays = (long)L * (n_scan - 1) * n, groups = (long)L * (n_scan - 1);
-        size_t need = tile_scratch_bytes(rays, groups);
+        // the wedges keep 6 bytes per ray (end cell, sorted ray number); the recorded walks of grid_mode 2 ~400
+        size_t need = wedges_ok(c, g) ? wedge_scratch_bytes(rays, groups, groups) : tile_scratch_bytes(rays, groups);
         if (need > c->tiles.cap) {
             if (c->gstream) HIPCHK(hipStreamSynchronize(c->gstream));
             TRY(arena_reserve(c, c->tiles, need));
@@ -933,6 +977,7 @@ int slam_grid_finalize_dev(slam_ctx *c, slam_grid *g, int8_t *pmap_dev)
 {
     TRY(use(c));
     REQUIRE(g && pmap_dev, "null pointer");
+    TRY(join_particles(c));        // (a chunked particle batch casts on a stream of its own)
     TRY(fork_to_grid(c));          // pmap_dev may still be in use by work on the main stream
     if (g->pmap_live) {            // kept current by the ray casts; refresh only if something bypassed that
         TRY(refresh_live(c, g, gs(c)));
@@ -1199,7 +1244,6 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
                        void *pts_ws, double *poses_out, double *T_out, int32_t *iters_out)
 {
     TRY(use(c));
-    TRY(grid_on_main(c));
     REQUIRE(ranges2 && cos_t && sin_t && pose_prev && poses_out && T_out, "null pointer");
     (void)pts_ws;   // kept in the ABI; the point buffers are no longer materialised
     REQUIRE(P > 0 && n > 0 && n <= 8192, "need P > 0 and 0 < n <= 8192");
@@ -1208,33 +1252,89 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
     REQUIRE(ds, "unknown dtype");
     REQUIRE(!grid || grid->d.G >= P, "the grid object needs one map per particle");
     REQUIRE(!grid || P <= 65535, "at most 65535 particles per call when ray casting");
-    {
-        IcpArgs a;
-        a.tar = a.src = nullptr; a.prior = prior;
-        a.ranges = ranges2; a.cos_t = cos_t; a.sin_t = sin_t;
-        a.tar_scan_stride = a.src_scan_stride = 0;   // every hypothesis matches the same scan pair
-        a.tar_stride = a.src_stride = 0;
-        a.ppt = 0;
-        a.B = P; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
-        a.T_out = T_out; a.iters_out = iters_out; a.err_out = nullptr;
-        a.status = c->status; a.qpt_pref = c->icp_qpt; a.team_mode = c->icp_team;
-        Timed t(c, SLAM_K_ICP);
-        HIPCHK(launch_icp(a, dtype, c->stream));
+    // Chunks (option "particle_chunks", off by default): matcher and pose step of chunk k on the context's stream, its ray
+    // cast on a second stream behind an event, beside the matcher of chunk k + 1.  The matcher is bound by vector issue and
+    // the ray cast by memory traffic, so the two should share the chip well - they do not (measured, round 4: 10 000
+    // hypotheses 1.14 ms per step in one piece, 1.19 / 1.35 / 1.61 in 2 / 4 / 8 chunks): a ray-cast workgroup holds half a
+    // CU's LDS for its window and the matcher's workgroups a quarter of its registers each, both for their whole lives, so
+    // workgroups of the two kernels displace each other on a CU instead of filling each other's stalls.
+    // Kept as an option because the chunks are also the unit a caller could overlap with work of its own; hypotheses are
+    // independent (ICP.process / Mapping.update per hypothesis), so chunking changes no result.
+    int chunks = c->particle_chunks > 1 ? c->particle_chunks : 1;
+    if (!grid || chunks > P) chunks = 1;
+    if (chunks == 1) TRY(grid_on_main(c));
+    else if (c->pipeline) TRY(join_from_grid(c));
+    if (chunks > 1) {
+        if (!c->pstream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->pev_join, hipEventDisableTiming));
+        }
+        while ((int)c->pev_pose.size() < chunks) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            c->pev_pose.push_back(e0);
+            c->pev_cast.push_back(e1);
+        }
+        // casts of an earlier batch may still read poses_out / the heading scratch: a batch of the same shape waits for
+        // them chunk by chunk (below), any other waits for all of them
+        if (c->pdirty && (c->p_last_P != P || c->p_last_chunks != chunks || c->p_last_poses != poses_out)) TRY(join_particles(c));
     }
     double *heading_cs = nullptr;               // cos / sin of the new headings: written by the pose step, read by the ray cast
     if (grid) {
-        TRY(arena_reserve(c, c->scratch, align_up((size_t)P * 16) + 1024));
+        const size_t need = align_up((size_t)P * 16) + 1024;
+        if (need > c->scratch.cap && c->pstream) {   // (the arena is about to be re-allocated: nothing may still read it)
+            TRY(join_particles(c));
+            HIPCHK(hipStreamSynchronize(c->pstream));
+        }
+        TRY(arena_reserve(c, c->scratch, need));
         heading_cs = carve<double>(c->scratch, (size_t)P * 2);
-    }
-    {
-        Timed t(c, SLAM_K_COMPOSE);
-        HIPCHK(launch_pose_compose(T_out, pose_prev, P, 1, poses_out, c->stream, prior, heading_cs));
-    }
-    if (grid) {
         grid->pristine = false;
-        Timed t(c, SLAM_K_GRID);
-        HIPCHK(launch_grid_update_replay_win(grid->d, ranges2, cos_t, sin_t, poses_out, P, 2, n, nullptr, 1, c->stream,
-                                             /*shared_scans=*/1, /*grid_per_traj=*/1, heading_cs));
+    }
+    for (int k = 0; k < chunks; ++k) {
+        const int p0 = (int)((long)P * k / chunks), pc = (int)((long)P * (k + 1) / chunks) - p0;
+        {
+            IcpArgs a;
+            a.tar = a.src = nullptr; a.prior = prior ? prior + 6 * (size_t)p0 : nullptr;
+            a.ranges = ranges2; a.cos_t = cos_t; a.sin_t = sin_t;
+            a.tar_scan_stride = a.src_scan_stride = 0;   // every hypothesis matches the same scan pair
+            a.tar_stride = a.src_stride = 0;
+            a.ppt = 0;
+            a.B = pc; a.n_tar = n; a.n_src = n; a.max_iter = max_iter; a.tol = tol;
+            a.T_out = T_out + 9 * (size_t)p0; a.iters_out = iters_out ? iters_out + p0 : nullptr; a.err_out = nullptr;
+            a.status = c->status; a.team_mode = c->icp_team;
+            // (queries per lane by the size of the BATCH: its chunks share the chip with one another's ray casts)
+            a.qpt_pref = c->icp_qpt > 0 ? c->icp_qpt : (P >= 2500 ? 3 : 0);
+            Timed t(c, SLAM_K_ICP, nullptr, k == 0);
+            HIPCHK(launch_icp(a, dtype, c->stream));
+        }
+        if (chunks > 1 && c->pdirty && c->p_last_chunks == chunks)      // the previous batch's cast of this chunk has read poses / headings
+            HIPCHK(hipStreamWaitEvent(c->stream, c->pev_cast[k], 0));
+        {
+            Timed t(c, SLAM_K_COMPOSE, nullptr, k == 0);
+            HIPCHK(launch_pose_compose(T_out + 9 * (size_t)p0, pose_prev + 3 * (size_t)p0, pc, 1, poses_out + 3 * (size_t)p0, c->stream,
+                                       prior ? prior + 6 * (size_t)p0 : nullptr, heading_cs ? heading_cs + 2 * (size_t)p0 : nullptr));
+        }
+        if (grid) {
+            hipStream_t st = c->stream;
+            if (chunks > 1) {
+                HIPCHK(hipEventRecord(c->pev_pose[k], c->stream));
+                HIPCHK(hipStreamWaitEvent(c->pstream, c->pev_pose[k], 0));
+                st = c->pstream;
+            }
+            GridDev d = grid->d;                                       // the chunk's maps
+            const size_t off = (size_t)p0 * d.xw * d.yw;
+            d.G = pc; d.pass += off; d.hit += off;
+            if (d.pmap_live) d.pmap_live += off;
+            Timed t(c, SLAM_K_GRID, nullptr, k == 0);
+            HIPCHK(launch_grid_update_replay_win(d, ranges2, cos_t, sin_t, poses_out + 3 * (size_t)p0, pc, 2, n, nullptr, 1, st,
+                                                 /*shared_scans=*/1, /*grid_per_traj=*/1, heading_cs + 2 * (size_t)p0));
+            if (chunks > 1) HIPCHK(hipEventRecord(c->pev_cast[k], c->pstream));
+        }
+    }
+    if (chunks > 1) {
+        c->pdirty = true;
+        c->p_last_P = P; c->p_last_chunks = chunks; c->p_last_poses = poses_out;
     }
     return SLAM_OK;
 }

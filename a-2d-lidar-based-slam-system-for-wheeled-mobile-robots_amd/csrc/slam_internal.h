@@ -38,8 +38,9 @@ inline bool launch_events(hipEvent_t *e0, hipEvent_t *e1)
     } while (0)
 
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remembered per (device, function), so a
-// second device used by the same process gets the attribute too.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: the largest size set so far is remembered
+// per (device, function), so a second device used by the same process gets the attribute too and a later launch that
+// needs more LDS than any before it raises it.
 hipError_t allow_dynamic_lds(const void *kernel, int bytes);
 
 constexpr int kWave = 64;
@@ -165,7 +166,9 @@ hipError_t launch_grid_update_replay_win(const GridDev &g, const float *ranges, 
 hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int S, int n, int group, hipStream_t s, int split_pref = -1);
 // Tiled path for maps much larger than an LDS window (single shared map, ReplaySource only).
+constexpr int kTileMaxBeams = 8192;      // beams per scan the tiled / wedge paths take (ray numbers inside a group are 16-bit)
 size_t tile_scratch_bytes(long rays, long groups);
+size_t wedge_scratch_bytes(long rays, long scans, long groups);
 bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj);
 hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int L, int n_scan, int n, int group,

@@ -30,12 +30,17 @@
     do {                                                                                                 \
         if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), (unsigned long long)(v)); \
     } while (0)
+#define STAMP_WAVE_COUNT(k, v)   /* lane 0 of every wave adds v (wave-uniform) to counter k */                     \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), (unsigned long long)(v)); \
+    } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_END(k)
 #define STAMP_SYNC()
 #define STAMP_COUNT(k, v)
+#define STAMP_WAVE_COUNT(k, v)
 #endif
 
 // Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles

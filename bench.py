@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--config", default="replay", choices=sorted(CONFIGS))
     ap.add_argument("--scans", type=int, default=None, help="processed scans per trajectory (default 1000; 5000 with --gpus > 1)")
     ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--particle-chunks", type=int, default=0, help="particles: chunks a batch is cut into (scan matching of chunk k + 1 beside the ray cast of chunk k); 0: the library's choice, 1: off")
+    ap.add_argument("--pose-spread", type=float, default=0.0, help="particles: standard deviation of the hypotheses' previous poses (m, m, rad); 0: all at the origin (SURVEY.md 8d cfg3)")
     ap.add_argument("--beams", type=int, default=None)
     ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--reso", type=float, default=None)
@@ -364,7 +366,7 @@ class ParticleWorkload:
         self.mats = slam.prior_matrices(slam.synthetic.particle_priors(P, seed=2 + rank))
         # the hypotheses differ by their prior perturbation only; every particle
         # starts the step at the same pose (tests/test_gpu_configs.py also runs scattered poses)
-        self.pose_prev = np.zeros((P, 3))
+        self.pose_prev = np.zeros((P, 3)) if not args.pose_spread else np.random.default_rng(4 + rank).normal(0, args.pose_spread, size=(P, 3))
         self.shared = dict(ranges2=d(self.rep.ranges.astype(np.float32)), cos_t=d(ct), sin_t=d(st), prior=d(self.mats.reshape(P, 6)),
                            pose_prev=d(self.pose_prev))
 
@@ -375,6 +377,8 @@ class ParticleWorkload:
             ln = Lane()
             ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
             ln.ctx = A.Context(local, ln.stream.cuda_stream)
+            # one lane = kernels back to back (the stand-alone durations the rooflines use): no chunks
+            ln.ctx.set_option("particle_chunks", args.particle_chunks if n_lanes > 1 or args.lanes == 1 else 1)
             ln.t = dict(poses=torch.empty((P, 3), dtype=torch.float64, device=self.dev),
                         T=torch.empty((P, 9), dtype=torch.float64, device=self.dev),
                         iters=torch.empty(P, dtype=torch.int32, device=self.dev))
@@ -399,7 +403,7 @@ class ParticleWorkload:
                                           a.beams, A.DTYPES[a.points], sh["prior"].data_ptr(), sh["pose_prev"].data_ptr(), self.P,
                                           a.max_iter, a.tol, ln.grid._h, None, t["poses"].data_ptr(), t["T"].data_ptr(),
                                           t["iters"].data_ptr()))
-        A.check(self.L.slam_grid_finalize_dev(ln.ctx.handle, ln.grid._h, ln.pmap_ptr))
+        # (no finalize call: the ray cast keeps the live pmap current, ln.pmap_ptr IS the result)
         ln.done += 1
         self.done += 1
         return None, self.done - 1

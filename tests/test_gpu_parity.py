@@ -787,3 +787,126 @@ def test_particle_hypotheses_pipeline_vs_oracle(slam, syn):
         r = grid.read(p, want=("pmap", "pass", "hit"))
         assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), p
     assert len(set(it.tolist())) > 1
+
+
+@pytest.mark.parametrize("P", [5, 64])
+def test_particle_hypotheses_without_priors(slam, syn, P):
+    """slam_particles with prior == NULL and a small batch: the ray cast reads cos / sin of the new headings from the
+    pose step's scratch, so the pose step must be the kernel that writes them whatever the batch size (until round 4 a
+    batch of <= 64 hypotheses without priors took k_pose_compose, which does not, and the maps were cast with stale
+    scratch bytes for a heading)."""
+    rep = syn.make_replay(2, 360, seed=5, stride=5)
+    pose_prev = np.random.default_rng(6).normal(0, 0.5, size=(P, 3))
+    grid = slam.DeviceGrid.metric(P, 400, 400, 0.05)
+    # (a second batch right behind one WITH priors, whose headings differ: stale scratch would show)
+    slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, slam.prior_matrices(syn.particle_priors(P, seed=3)), pose_prev + 1.0, grid=None)
+    poses, T, it = slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, None, pose_prev, grid=grid)
+    tar = np.array(co.laser_to_points(rep.ranges[0], AMIN, AMAX))
+    src = np.array(co.laser_to_points(rep.ranges[1], AMIN, AMAX))
+    oT, oit, _ = co.icp_process(tar, src, 30, 0.001)
+    for p in range(P):
+        op = co.compose_pose(pose_prev[p], oT)
+        assert it[p] == oit and np.max(np.abs(T[p] - oT)) < FTOL and np.max(np.abs(poses[p] - op)) < FTOL, p
+        og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+        ox, oy = co.world_points(op, src[0], src[1])
+        og.update(ox, oy, op[0], op[1])
+        r = grid.read(p, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), p
+    grid.close()
+
+
+def test_wedge_sort_lds_need_grows_within_one_process(slam):
+    """k_wedge_sort's dynamic LDS depends on beams x scans per group: a cast with few beams (attribute set to a few KB)
+    followed by one that needs more than the 64 KB default must raise the attribute again (allow_dynamic_lds remembers
+    the largest size per kernel, not just that it was set)."""
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", 4)
+    rng = np.random.default_rng(21)
+    for B, n in ((16, 96), (16, 2040), (3, 8192)):               # 16 x 2040 rays: 2 x 32 640 B of keys + bins > 64 KB
+        cx, cy = rng.uniform(-2, 2, B), rng.uniform(-2, 2, B)
+        ang, d = rng.uniform(-np.pi, np.pi, (B, n)), rng.uniform(0.1, 9.0, (B, n))
+        ox, oy = cx[:, None] + np.cos(ang) * d, cy[:, None] + np.sin(ang) * d
+        g = slam.DeviceGrid(1, 300, 280, 12.5, 12.0, 11.2, context=ctx)
+        g.update_host(ox, oy, cx, cy)
+        og = co.Grid(300, 280, 12.5, 12.0, 11.2)
+        for b in range(B):
+            og.update(ox[b], oy[b], cx[b], cy[b])
+        r = g.read(0, want=("pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and g.visits() == og.visits, (B, n)
+        g.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", [2, 4])
+def test_forced_tiled_modes_keep_the_beam_bound(slam, mode):
+    """grid_mode 2 / 4 force the tiled / wedge path only up to 8192 beams per scan (ray numbers inside a group are
+    16-bit); a scan with more beams takes the window / direct path instead of being cast with truncated ray numbers."""
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", mode)
+    rng = np.random.default_rng(22)
+    for n in (8193, 70001):
+        ang, d = rng.uniform(-np.pi, np.pi, n), rng.uniform(0.1, 9.0, n)
+        ox, oy = 0.3 + np.cos(ang) * d, -0.2 + np.sin(ang) * d
+        g = slam.DeviceGrid(1, 200, 200, 10.0, 10.0, 10.0, context=ctx)
+        g.update_host(ox, oy, 0.3, -0.2)
+        og = co.Grid(200, 200, 10.0, 10.0, 10.0)
+        og.update(ox, oy, 0.3, -0.2)
+        r = g.read(0, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), n
+        assert g.visits() == og.visits
+        g.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [120, 360])
+@pytest.mark.parametrize("offset", [(1000.0, -700.0), (-3.0e4, 2.5e4)])
+def test_icp_clouds_far_from_the_origin_one_pass_products(slam, syn, n, offset):
+    """From its second iteration on k_icp forms the centred cross-covariance in ONE pass about the previous matches'
+    centroid p, W = sum (b - p)(a - p)^T - S_b S_a^T / N, where the reference centres first (icp.py:154-160).  The two
+    differ by roundings of the order of W's last place as long as p is close to the centroids - which the
+    coordinates' magnitude must not change: clouds 1e3 and 4e4 m from the origin (coordinates 200 to 8000 times the
+    clouds' spread), iteration counts equal and transforms to 1e-9 (relative to the offset for the translation)."""
+    reps = [syn.make_replay(9, n, seed=40 + s, stride=5) for s in range(3)]
+    tars, srcs = [], []
+    for rep in reps:
+        pts = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges])
+        pts[:, 0, :] += offset[0]
+        pts[:, 1, :] += offset[1]
+        tars.append(pts[:-1]); srcs.append(pts[1:])
+    tars, srcs = np.concatenate(tars), np.concatenate(srcs)
+    T, it, err = slam.icp_batch_host(tars, srcs, 30, 0.001)
+    oT, oit, oerr = co.icp_batch(tars, srcs, 30, 0.001)
+    assert np.array_equal(it, oit), (it, oit)
+    assert int(it.max()) >= 3                                    # the one-pass iterations really ran
+    scale = max(abs(offset[0]), abs(offset[1]))
+    assert np.max(np.abs(T[:, :2, :2] - oT[:, :2, :2])) < FTOL
+    assert np.max(np.abs(T[:, :2, 2] - oT[:, :2, 2])) < FTOL * scale
+    assert np.max(np.abs(err - oerr)) < FTOL
+
+
+def test_particle_batch_in_chunks_is_identical(slam, syn):
+    """Context option "particle_chunks": the batch is cut into chunks whose ray casts run on a second stream behind the
+    next chunk's scan matching.  Hypotheses are independent, so poses, transforms, iteration counts and every map must
+    equal the one-piece batch bit for bit - also when a second batch follows while the first one's casts may still run."""
+    rep = syn.make_replay(2, 360, seed=2, stride=5)
+    P = 50
+    mats = slam.prior_matrices(syn.particle_priors(P, seed=8))
+    pose_prev = np.random.default_rng(9).normal(0, 0.5, size=(P, 3))
+    out = {}
+    for chunks in (1, 3, 7):
+        ctx = slam.Context(0)
+        ctx.set_option("particle_chunks", chunks)
+        grid = slam.DeviceGrid.metric(P, 400, 400, 0.05, context=ctx)
+        grid.live_pmap()
+        for _ in range(2):                                       # the second batch meets settled maps
+            poses, T, it = slam.particles_host(rep.ranges[0], rep.ranges[1], AMIN, AMAX, mats, pose_prev, grid=grid, context=ctx)
+        maps = [grid.read(p, want=("pmap", "pass", "hit")) for p in range(P)]
+        out[chunks] = (poses, T, it, maps, grid.visits())
+        grid.close()
+        ctx.close()
+    for chunks in (3, 7):
+        a, b = out[1], out[chunks]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]
+        for p in range(P):
+            for k in ("pmap", "pass", "hit"):
+                assert np.array_equal(a[3][p][k], b[3][p][k]), (chunks, p, k)
