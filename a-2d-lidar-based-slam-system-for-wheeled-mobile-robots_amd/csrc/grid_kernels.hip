@@ -533,12 +533,13 @@ __device__ __forceinline__ unsigned cast_rays_strip(const GridDev &g, const Src 
     return nvis;
 }
 
-constexpr int kWinBoxInts = 48 + 64;   // bbox[4], window[4], flags; from [16]: the two direction halves; from [48]: every scan's first bad beam (k_grid_update_win)
+constexpr int kWinPhase = 48 + 64;     // box[]: from here the phases of k_grid_update_win (windows [4][8], phase of a quadrant [4], boundaries in the sorted order [5])
+constexpr int kWinBoxInts = kWinPhase + 48;   // bbox[4], flags; from [16]: the boxes of the four direction quadrants; from [48]: every scan's first bad beam (k_grid_update_win)
 __host__ __device__ inline size_t win_sc_bytes(int group) { return ((size_t)group * sizeof(ScanConst) + 15) & ~(size_t)15; }
 __host__ __device__ inline int win_sort_cap(long rays) { return rays <= kMaxSortRays ? (int)((rays + 7) & ~7L) : 0; }   // 16-byte multiple
 __host__ __device__ inline size_t win_lds_bytes(int group, int sort_cap, int win_cells)
 {
-    return win_sc_bytes(group) + kWinBoxInts * 4 + 2 * kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)win_cells * 2 + kLdsGuard;
+    return win_sc_bytes(group) + kWinBoxInts * 4 + 4 * kSortBins * 4 + (size_t)sort_cap * 2 + (size_t)win_cells * 2 + kLdsGuard;
 }
 // Window capacity (16-bit cells) of a launch: kWinCells, or, for small groups, whatever still lets two
 // workgroups share a CU's 160 KiB (a single 360-beam scan: 40 288 cells instead of 36 864 - the
@@ -560,8 +561,8 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     // second workgroup on the CU
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                  // [group_size]
     int *box = reinterpret_cast<int *>(smem + win_sc_bytes(group_size));                  // bbox[4], window[4], flags
-    int *hist = box + kWinBoxInts;                                                        // [2][kSortBins]
-    unsigned short *order = reinterpret_cast<unsigned short *>(hist + 2 * kSortBins);     // [sort_cap]
+    int *hist = box + kWinBoxInts;                                                        // [4][kSortBins]: (phase, length bin)
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + 4 * kSortBins);     // [sort_cap]
     unsigned *win = reinterpret_cast<unsigned *>(order + sort_cap);                       // [W][Hp/2] dwords
     char *guard = reinterpret_cast<char *>(win) + (size_t)win_cells * 2;
     lds_guard_fill(guard);
@@ -590,63 +591,71 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     unsigned long long *wg_visits = reinterpret_cast<unsigned long long *>(box + 12);
     if (tid == 0) {
         box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN; box[9] = 0; *wg_visits = 0ull;
-        box[16] = box[17] = box[20] = box[21] = INT_MAX; box[18] = box[19] = box[22] = box[23] = INT_MIN;
-        box[34] = 1; box[35] = 0;
+        for (int q = 0; q < 4; ++q) { box[16 + 4 * q] = box[17 + 4 * q] = INT_MAX; box[18 + 4 * q] = box[19 + 4 * q] = INT_MIN; }
+        box[34] = 1; box[36] = 0;
     }
     const bool sorted = nrays <= sort_cap;
-    // Direction halves (DESIGN.md "K4 halves"): a ray never crosses the column of its origin, so the
-    // rays that run towards larger x and those that run towards smaller x touch two disjoint halves of
-    // the group's bounding box (up to the few columns the origins of the group's scans differ by).
-    // When the whole box does not fit the window - a 10 m x 8 m room seen at an angle spans 250 x 250
-    // cells, 1.5 windows - each half gets the window to itself, one after the other: every ray is still
-    // walked once, and none of its cells takes the scattered-global-atomic path (40 % of the walk before).
-    const bool halves_ok = sorted && !exclusive && !split;
+    // Direction quadrants (DESIGN.md "K4a"): a Bresenham path stays in the box of its two ends, so a ray never crosses the
+    // column or the row of its origin, and the rays of the four direction quadrants (end cell right / left of, above / below
+    // the origin) touch four nearly disjoint parts of the group's bounding box (up to the few cells the origins of the
+    // group's scans differ by).  When the box of a workgroup's rays does not fit the window - a 10 m x 8 m room seen at an
+    // angle spans 250 x 250 cells, 1.5 windows - it is cut at the origins' column, and a half that still does not fit at their
+    // row: every part gets the window to itself, one PHASE after the other; every ray is still walked once, and none of
+    // its cells takes the checked walk with scattered global atomics (round 4 stamps: 44 of a replay's 250 workgroups had a
+    // half that did not fit; their walk took 109 k cycles against 36 k, and the launch lasted as long as they did).
+    const bool quads = sorted && !exclusive;
     unsigned short *bins = reinterpret_cast<unsigned short *>(win);   // scratch until the window is zeroed
-    for (int k = tid; k < 2 * kSortBins; k += blockDim.x) hist[k] = 0;
+    for (int k = tid; k < 4 * kSortBins; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     STAMP(0);                                   // scan constants
 
-    // pass 1: bounding box of everything the group's rays can touch
+    // pass 1: bounding box of everything the group's rays can touch, and of the four quadrants' rays
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
-    int hb[2][4] = {{INT_MAX, INT_MAX, INT_MIN, INT_MIN}, {INT_MAX, INT_MAX, INT_MIN, INT_MIN}};   // boxes of the two halves
+    int qb[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { qb[q][0] = qb[q][1] = INT_MAX; qb[q][2] = qb[q][3] = INT_MIN; }
     for (int r = tid; r < nrays; r += blockDim.x) {
-        int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0, side = 0;
-        if (src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2)) {
-            side = pox >= sc[s].pcx ? 1 : 0;
-            if (split && side != my_half) {                          // the other workgroup's ray (an error of the beam is both's: b2 is 0 here)
-                bins[r] = 0xffffu;
-                continue;
-            }
+        int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0, quad = 0;
+        const bool valid = src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2);
+        if (valid) {
+            quad = (pox >= sc[s].pcx ? 1 : 0) | (poy >= sc[s].pcy ? 2 : 0);
             const int rx0 = min(pox, sc[s].pcx), rx1 = max(pox, sc[s].pcx), ry0 = min(poy, sc[s].pcy), ry1 = max(poy, sc[s].pcy);
             bx0 = min(bx0, rx0); bx1 = max(bx1, rx1);
             by0 = min(by0, ry0); by1 = max(by1, ry1);
             len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
+            if (quads) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                hb[h][0] = side == h ? min(hb[h][0], rx0) : hb[h][0]; hb[h][1] = side == h ? min(hb[h][1], ry0) : hb[h][1];
-                hb[h][2] = side == h ? max(hb[h][2], rx1) : hb[h][2]; hb[h][3] = side == h ? max(hb[h][3], ry1) : hb[h][3];
+                for (int q = 0; q < 4; ++q) {
+                    qb[q][0] = quad == q ? min(qb[q][0], rx0) : qb[q][0]; qb[q][1] = quad == q ? min(qb[q][1], ry0) : qb[q][1];
+                    qb[q][2] = quad == q ? max(qb[q][2], rx1) : qb[q][2]; qb[q][3] = quad == q ? max(qb[q][3], ry1) : qb[q][3];
+                }
             }
         }
         // a scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before
         // it have been applied when the exception leaves update(), and the error is that beam's)
         if (b2) atomicMin(&fb[s], i);
-        if (sorted) {                                                // bin by (half,) length, longest first
-            int bin = kSortBins - 1 - min(len >> 2, kSortBins - 1) + (halves_ok ? side * kSortBins : 0);
-            if (split && len == 0 && my_half != 0) bin = 0xffff;     // (skipped / invalid beams: nothing to cast, half 0 keeps them)
-            bins[r] = (unsigned short)bin;                           // parked in the (not yet zeroed) window
-            if (bin != 0xffff) atomicAdd(&hist[bin], 1);
+        if (sorted) {                                                // bin by (phase,) length, longest first
+            const int lbin = kSortBins - 1 - min(len >> 2, kSortBins - 1);
+            if (quads) {
+                // which phase of which workgroup casts this ray is decided behind the barrier, when the boxes are known
+                // (bits 7-8: quadrant, bit 9: beam parity); rays with nothing to cast are nobody's
+                bins[r] = (valid && len > 0) ? (unsigned short)(lbin | (quad << 7) | ((i & 1) << 9)) : (unsigned short)0xffffu;
+            } else {
+                bins[r] = (unsigned short)lbin;                      // parked in the (not yet zeroed) window
+                atomicAdd(&hist[lbin], 1);
+            }
         }
     }
     bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0); bx1 = wave_max_i32(bx1); by1 = wave_max_i32(by1);
     if (lane == 0 && bx0 <= bx1) {
         atomicMin(&box[0], bx0); atomicMin(&box[1], by0); atomicMax(&box[2], bx1); atomicMax(&box[3], by1);
     }
-    if (halves_ok) {
+    if (quads) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int a0 = wave_min_i32(hb[h][0]), a1 = wave_min_i32(hb[h][1]), a2 = wave_max_i32(hb[h][2]), a3 = wave_max_i32(hb[h][3]);
+        for (int q = 0; q < 4; ++q) {
+            const int a0 = wave_min_i32(qb[q][0]), a1 = wave_min_i32(qb[q][1]), a2 = wave_max_i32(qb[q][2]), a3 = wave_max_i32(qb[q][3]);
             if (lane == 0 && a0 <= a2) {
-                atomicMin(&box[16 + 4 * h], a0); atomicMin(&box[17 + 4 * h], a1); atomicMax(&box[18 + 4 * h], a2); atomicMax(&box[19 + 4 * h], a3);
+                atomicMin(&box[16 + 4 * q], a0); atomicMin(&box[17 + 4 * q], a1); atomicMax(&box[18 + 4 * q], a2); atomicMax(&box[19 + 4 * q], a3);
             }
         }
     }
@@ -656,7 +665,72 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
         (void)src.ray(l, s0 + tid, fb[tid], sc[tid], g, pox, poy, b2);
         atomicOr(g.status, b2);
     }
-    if (tid == 0) {
+    int *phw = box + kWinPhase;                                      // [4][8] window of a phase: x0, y0, W, H, covers
+    int *phq = box + kWinPhase + 32;                                 // [4] phase of a quadrant's rays (-1: not this workgroup's)
+    int *seg = box + kWinPhase + 36;                                 // [5] boundaries of the phases in the sorted order
+    if (tid == 0 && quads) {
+        // union of the quadrants in mask -> clamped box; false: empty
+        auto box_of = [&](unsigned mask, int *o) -> bool {
+            o[0] = o[1] = INT_MAX; o[2] = o[3] = INT_MIN;
+            for (int q = 0; q < 4; ++q)
+                if ((mask >> q & 1u) && box[16 + 4 * q] <= box[18 + 4 * q]) {
+                    o[0] = min(o[0], box[16 + 4 * q]); o[1] = min(o[1], box[17 + 4 * q]); o[2] = max(o[2], box[18 + 4 * q]); o[3] = max(o[3], box[19 + 4 * q]);
+                }
+            o[0] = max(o[0], 0); o[1] = max(o[1], 0); o[2] = min(o[2], g.xw - 1); o[3] = min(o[3], g.yw - 1);
+            if (pair64) o[1] &= ~1;                                  // the window's dwords line up with 8-byte pairs of counters
+            return o[0] <= o[2] && o[1] <= o[3];
+        };
+        auto fits = [&](unsigned mask) -> bool {
+            int o[4];
+            return !box_of(mask, o) || (long)(o[2] - o[0] + 1) * ((o[3] - o[1] + 2) & ~1) <= win_cells;
+        };
+        // the parts (sets of quadrants) this workgroup casts, one phase each
+        unsigned part[4] = {0u, 0u, 0u, 0u};
+        int nph = 1, parity = 0;
+        if (split) {
+            // Two workgroups per group.  When the group's whole box fits one window, both take that window and share the
+            // rays evenly, by beam parity (neighbouring beams are about equally long; the direction halves of a scan taken
+            // off-centre differ up to 3 : 1 in cells to walk).  Else a workgroup per direction half, cut again at the
+            // origins' row if the half does not fit.
+            const unsigned mine = my_half ? 0xAu : 0x5u;             // quadrants right / left of the origins' column
+            if (fits(0xFu)) { part[0] = 0xFu; parity = 1; }
+            else if (fits(mine)) part[0] = mine;
+            else { part[0] = mine & 0x3u; part[1] = mine & 0xCu; nph = 2; }
+        } else {
+            if (fits(0xFu)) part[0] = 0xFu;
+            else if (fits(0x5u) && fits(0xAu)) { part[0] = 0x5u; part[1] = 0xAu; nph = 2; }
+            else { part[0] = 1u; part[1] = 2u; part[2] = 4u; part[3] = 8u; nph = 4; }
+        }
+        for (int q = 0; q < 4; ++q) phq[q] = -1;
+        for (int ph = 0; ph < nph; ++ph) {
+            for (int q = 0; q < 4; ++q)
+                if (part[ph] >> q & 1u) phq[q] = ph;
+            int o[4], W = 0, H = 0, cov = 1;
+            if (box_of(part[ph], o)) {
+                W = o[2] - o[0] + 1; H = o[3] - o[1] + 1;
+                if ((long)W * ((H + 1) & ~1) > win_cells) {
+                    // still too large: the sub-rectangle next to the origins (the rays start there; clamped into the part's
+                    // box, i.e. in its corner for a quadrant) and the rest by direct atomics
+                    const int Hd = min(H, 192), Wd = min(W, win_cells / ((Hd + 1) & ~1));   // rows are stored padded to an even height
+                    int cx0 = min(max(sc[0].pcx - Wd / 2, o[0]), o[2] - Wd + 1), cy0 = min(max(sc[0].pcy - Hd / 2, o[1]), o[3] - Hd + 1);
+                    if (pair64) cy0 &= ~1;
+                    o[0] = cx0; o[1] = cy0; W = Wd; H = Hd; cov = 0;
+                }
+                // the window is W rows of (H + 1) / 2 dwords: it must fit the win_cells 16-bit cells carved for it.  Should the
+                // sizing above ever be wrong (it once used the unpadded height: a 193 x 191 box wrote 96 dwords past the
+                // window), fall back to no window at all - every cell then takes the direct-atomic path, still exact - and
+                // raise the internal-error status bit.
+                if ((long)W * ((H + 1) >> 1) > win_cells / 2) { atomicOr(g.status, kStatusGuard); W = 0; H = 0; cov = 0; }
+            } else {
+                o[0] = o[1] = 0;
+            }
+            int *w = phw + 8 * ph;
+            w[0] = o[0]; w[1] = o[1]; w[2] = W; w[3] = H; w[4] = cov;
+        }
+        box[34] = nph; box[36] = parity;
+        box[10] = 0; box[11] = 0;
+    }
+    if (tid == 0 && !quads) {
         int x0 = max(box[0], 0), y0 = max(box[1], 0), x1 = min(box[2], g.xw - 1), y1 = min(box[3], g.yw - 1);
         int W = 0, H = 0, covers = 1;
         int fastwin = 0, strip_w = 0;                                // strips of the single-scan owner form
@@ -680,82 +754,67 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
                 x0 = cx0; y0 = cy0; W = Wd; H = Hd;
                 covers = 0;
             }
-            // the window is W rows of (H + 1) / 2 dwords: it must fit the win_cells 16-bit cells carved
-            // for it.  Should the sizing above ever be wrong again (it once used the unpadded height: a
-            // 193 x 191 box wrote 96 dwords past the window), fall back to no window at all - every cell
-            // then takes the direct-atomic path, still exact - and raise the internal-error status bit.
-            if ((long)(fastwin ? strip_w : W) * ((H + 1) >> 1) > win_cells / 2) {
+            if ((long)(fastwin ? strip_w : W) * ((H + 1) >> 1) > win_cells / 2) {   // (see above)
                 atomicOr(g.status, kStatusGuard);
                 fastwin = 0;
                 W = 0; H = 0; covers = 0;
             }
         }
-        box[4] = x0; box[5] = y0; box[6] = W; box[7] = H; box[8] = covers; box[10] = fastwin; box[11] = strip_w;
-        if (halves_ok && !covers && !fastwin && W > 0) {
-            // the whole box does not fit: one window per direction half.  A half that is still too large keeps
-            // the sub-rectangle next to the origin column (its rays start there) and leaves the rest to the
-            // direct atomics, as the whole box did.
-            bool any = false;
-            for (int h = 0; h < 2; ++h) {
-                int hx0 = max(box[16 + 4 * h], 0), hy0 = max(box[17 + 4 * h], 0), hx1 = min(box[18 + 4 * h], g.xw - 1), hy1 = min(box[19 + 4 * h], g.yw - 1);
-                int hW = 0, hH = 0, hc = 1;
-                if (hx0 <= hx1 && hy0 <= hy1) {
-                    if (pair64) hy0 &= ~1;
-                    hW = hx1 - hx0 + 1; hH = hy1 - hy0 + 1;
-                    if ((long)hW * ((hH + 1) & ~1) > win_cells) {
-                        int Hd = min(hH, 192), Wd = min(hW, win_cells / ((Hd + 1) & ~1));
-                        int cx0 = h ? hx0 : hx1 - Wd + 1, cy0 = min(max(sc[0].pcy - Hd / 2, hy0), hy1 - Hd + 1);
-                        if (pair64) cy0 &= ~1;
-                        hx0 = cx0; hy0 = cy0; hW = Wd; hH = Hd; hc = 0;
-                    }
-                    if ((long)hW * ((hH + 1) >> 1) > win_cells / 2) { atomicOr(g.status, kStatusGuard); hW = 0; hH = 0; hc = 0; }
-                    any = true;
-                }
-                int *o = h ? box + 24 : box + 4;
-                o[0] = hx0; o[1] = hy0; o[2] = hW; o[3] = hH; o[4] = hc;
-            }
-            if (any) box[34] = 2;
-        }
+        phw[0] = x0; phw[1] = y0; phw[2] = W; phw[3] = H; phw[4] = covers; box[10] = fastwin; box[11] = strip_w;
+        box[34] = 1; box[36] = 0;
+        seg[0] = 0; seg[1] = nrays;
     }
     __syncthreads();
-    STAMP(1);                                   // pass 1: endpoints, bounding box, histogram
-    int wx0 = box[4], wy0 = box[5], W = box[6], H = box[7];
-    bool covers = box[8] != 0;            // the window holds every in-map cell the group can touch
+    STAMP(1);                                   // pass 1: endpoints, bounding boxes, phases
+    int wx0 = phw[0], wy0 = phw[1], W = phw[2], H = phw[3];
+    bool covers = phw[4] != 0;            // the window holds every in-map cell the phase's rays can touch
     int Hp2 = (H + 1) >> 1;               // dwords per window row
-    const int phases = box[34];           // 2: one window per direction half
+    const int phases = box[34];
     if (sorted) {
-        // counting sort of the ray ids by (half,) length bin: exclusive scan of the histogram (wave 0),
-        // then every ray claims a slot in its bin.  Order inside a bin is arbitrary; the map
-        // update does not depend on ray order.
+        if (quads) {                                                 // this workgroup's rays and their phases
+            const bool parity = box[36] != 0;
+            for (int r = tid; r < nrays; r += blockDim.x) {
+                const unsigned b = bins[r];
+                if (b == 0xffffu) continue;
+                const int ph = phq[(b >> 7) & 3u];
+                const bool mine = ph >= 0 && (!parity || (int)((b >> 9) & 1u) == my_half);
+                const unsigned fin = (unsigned)ph * kSortBins + (b & 127u);
+                bins[r] = mine ? (unsigned short)fin : (unsigned short)0xffffu;
+                if (mine) atomicAdd(&hist[fin], 1);
+            }
+            __syncthreads();
+        }
+        // counting sort of the ray ids by (phase, length bin): exclusive scan of the histogram (wave 0), then every ray
+        // claims a slot in its bin.  Order inside a bin is arbitrary; the map update does not depend on ray order.
         if (wave == 0) {
-            int h4[4], tot = 0;
+            int h8[8], tot = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { h4[u] = hist[4 * lane + u]; tot += h4[u]; }
+            for (int u = 0; u < 8; ++u) { h8[u] = hist[8 * lane + u]; tot += h8[u]; }
             int inc = tot;
 #pragma unroll
             for (int off = 1; off < kWave; off <<= 1) { int v = __shfl_up(inc, off, kWave); if (lane >= off) inc += v; }
             int run = inc - tot;
-            if (lane == kSortBins / 4) box[35] = run;                // rays of half 0 (all of them without halves: unused)
+            if (quads && (lane & 15) == 0) seg[lane >> 4] = run;     // first bin of a phase: kSortBins / 8 = 16 lanes per phase
+            if (quads && lane == kWave - 1) seg[4] = inc;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { hist[4 * lane + u] = run; run += h4[u]; }
+            for (int u = 0; u < 8; ++u) { hist[8 * lane + u] = run; run += h8[u]; }
         }
         __syncthreads();
         for (int r = tid; r < nrays; r += blockDim.x)
             if (bins[r] != 0xffffu) order[atomicAdd(&hist[bins[r]], 1)] = (unsigned short)r;
         __syncthreads();
     }
-    const int nmine = split ? box[35] : nrays;                       // rays this workgroup casts (split: its half's, sorted)
     unsigned nvis = 0;
     const unsigned short *ord = sorted ? order : nullptr;
     const int strips = box[10], strip_w = box[11];
     const bool fast = strips != 0;        // single-scan owner form (the sweep at the end of the kernel)
     for (int ph = 0; ph < (fast ? 0 : phases); ++ph) {
-        int seg0 = 0, seg1 = nmine;
-        if (phases == 2) {
-            const int *o = ph ? box + 24 : box + 4;
+        const int seg0 = seg[ph], seg1 = seg[ph + 1];
+        if (seg0 == seg1) continue;                                   // (uniform) a part without rays
+        {
+            const int *o = phw + 8 * ph;
             wx0 = o[0]; wy0 = o[1]; W = o[2]; H = o[3]; covers = o[4] != 0; Hp2 = (H + 1) >> 1;
-            seg0 = ph ? box[35] : 0; seg1 = ph ? nrays : box[35];
-            if (ph) __syncthreads();                                  // the previous half's flush has read the window
+            __syncthreads();                                          // the previous phase's flush has read the window
             if (tid == 0) box[9] = 0;
         }
         for (int w = tid; w < W * Hp2; w += blockDim.x) win[w] = 0u;
@@ -940,6 +999,7 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     __syncthreads();
     if (tid == 0 && *wg_visits) atomicAdd(visit_slot(g.visits), *wg_visits);
     STAMP(4);                                   // flush / sweep
+    STAMP_VAL((box[36] << 8) | (covers ? 1 : 0) | (phases << 4) | ((unsigned)(W * ((H + 1) & ~1)) << 12));
     STAMP_END(5);                               // [5] lifetime, [6] workgroups
     lds_guard_check(guard, g.status);
 }
@@ -1711,7 +1771,17 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
     // that way (0.088 -> 0.078 ms); when launches of several contexts share the chip the duplicated first pass costs
     // 4 % of the throughput, so callers that overlap replays switch it off (context option "grid_split")
     const int split = (!exclusive && sort_cap > 0 && (split_pref > 0 || (split_pref < 0 && (long)groups * L <= 192))) ? 1 : 0;
-    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(split ? 2 * groups : groups, L), dim3(threads), win_lds_bytes(group, sort_cap, win_cells), s, g, src, group, got,
+    // A launch of at most one workgroup per CU asks for more than half a CU's LDS, so that no CU gets two of its workgroups
+    // while others stay empty: the dispatcher does not spread a small grid by itself (stamps, round 4: of 250 workgroups on
+    // 256 CUs the slowest took 1.8 x the mean with the same number of cells to walk - it shared its CU with another one).
+    size_t lds = win_lds_bytes(group, sort_cap, win_cells);
+    const long wgs = (long)(split ? 2 * groups : groups) * L;
+    if (split && wgs <= 256 && lds <= 80 * 1024) lds = 80 * 1024 + 512;
+    if (lds > lds_max) {
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_update_win<Src>), (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    SLAM_LAUNCH((k_grid_update_win<Src>), dim3(split ? 2 * groups : groups, L), dim3(threads), lds, s, g, src, group, got,
                 exclusive, sort_cap, win_cells, split);
     return hipGetLastError();
 }
@@ -2282,6 +2352,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
     unsigned *win = reinterpret_cast<unsigned *>(smem + 64);
     char *guard = reinterpret_cast<char *>(win) + (size_t)kWedgeCells * 2;
     lds_guard_fill(guard);
+    STAMP_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kWedgeThreads >> 6;
     const int cls = blockIdx.x;
     const long group = blockIdx.y;
@@ -2323,6 +2394,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
         amin = wave_min_i32(amin); amax = wave_max_i32(amax);
         if (lane == 0 && amin <= amax) { atomicMin(&box[0], amin); atomicMax(&box[1], amax); }
         __syncthreads();
+        STAMP(0);                                   // ray set-up
         const int a_first = box[0] & ~1, a_end = box[1];               // (even band starts: pairs of counters line up for the flush)
         for (int a_lo = a_first; a_lo <= a_end;) {
             // rows of this band (even): try what is left (at most 512), shrink to what the parallelogram's width allows.
@@ -2387,6 +2459,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
             for (int w4 = tid; w4 < (P * C) >> 3; w4 += kWedgeThreads) reinterpret_cast<uint4 *>(win)[w4] = make_uint4(0u, 0u, 0u, 0u);
             for (int w1 = ((P * C) >> 3) * 4 + tid; w1 < (P * C) >> 1; w1 += kWedgeThreads) win[w1] = 0u;
             __syncthreads();
+            STAMP(1);                               // band geometry + zero
             const int dh_a = ca - M * cv;
 #pragma unroll
             for (int j = 0; j < kWedgeSlots; ++j) {
@@ -2418,6 +2491,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
                 w.error = error; w.y = y; w.k += took;
             }
             __syncthreads();
+            STAMP(3);                               // walk
             // flush: a wave per MAP row (map x), lanes along map y, two cells per lane as one 64-bit add where the pair is
             // aligned.  Not steep, or steep without shear: a map row is a physical row of the window.  Steep with shear: the
             // cells of map row x lie on a diagonal of the window (column c = map y - a_lo in physical row x - M y - v_lo),
@@ -2453,8 +2527,10 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
             }
             a_lo += rows;
             __syncthreads();
+            STAMP(4);                               // flush
         }
     }
+    STAMP_END(5);
     lds_guard_check(guard, g.status);
 }
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "slam_internal.h"
+#include "slam_stamps.h"
 
 using namespace slam;
 
@@ -420,8 +421,13 @@ int slam_create(int device, void *stream, slam_ctx **out)
         }
         c->own_stream = true;
     }
-    e = hipMalloc(reinterpret_cast<void **>(&c->status), 256);
-    if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 256, c->stream);
+#ifdef SLAM_STAMPS
+    const size_t status_bytes = 256 + (size_t)kStampRecords * 32;   // diagnostic build: per-workgroup phase records behind the status block
+#else
+    const size_t status_bytes = 256;
+#endif
+    e = hipMalloc(reinterpret_cast<void **>(&c->status), status_bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, status_bytes, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         delete c;
@@ -553,6 +559,17 @@ int slam_debug_read(slam_ctx *c, void *out256, int clear)
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out256, c->status, 256, hipMemcpyDeviceToHost));
     if (clear) HIPCHK(hipMemset(reinterpret_cast<char *>(c->status) + 32, 0, 224));
+    return SLAM_OK;
+}
+#endif
+#ifdef SLAM_STAMPS
+/* diagnostic build: the per-workgroup records (8 dwords each, slam_stamps.h) of the launches since the last clear */
+int slam_debug_records(slam_ctx *c, void *out, int max_records)
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int n = max_records < kStampRecords ? max_records : kStampRecords;
+    HIPCHK(hipMemcpy(out, reinterpret_cast<char *>(c->status) + 256, (size_t)n * 32, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 #endif

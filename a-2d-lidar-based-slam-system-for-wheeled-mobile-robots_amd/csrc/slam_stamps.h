@@ -8,12 +8,16 @@
 
 // ---- grid kernels: STAMP_DECL at kernel entry, STAMP(k) closes phase k, STAMP_END(k): [k] lifetime, [k + 1] workgroups
 #ifdef SLAM_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0
+// (behind the 256-byte status block the stamps build allocates kStampRecords records of 8 dwords, one per workgroup in the
+// order they finish: phases 0..4 in shader cycles, lifetime, blockIdx.x | blockIdx.y << 16, a value of the kernel's choice (STAMP_VAL; else the start on the 100 MHz clock))
+constexpr int kStampRecords = 32768;
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0; unsigned st_rec[5] = {0u, 0u, 0u, 0u, 0u}; unsigned st_real = (unsigned)__builtin_amdgcn_s_memrealtime()
 #define STAMP(k)                                                                                         \
     do {                                                                                                 \
         if (threadIdx.x == 0) {                                                                          \
             unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
             atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_t0);           \
+            st_rec[(k) < 5 ? (k) : 4] += (unsigned)(t_ - st_t0);                                         \
             st_t0 = t_;                                                                                  \
         }                                                                                                \
     } while (0)
@@ -22,9 +26,15 @@
         if (threadIdx.x == 0) {                                                                          \
             unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
             atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k), t_ - st_first);        \
-            atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k) + 1, 1ull);             \
+            const unsigned long long id_ = atomicAdd(reinterpret_cast<unsigned long long *>(g.status + 8) + (k) + 1, 1ull); \
+            if (id_ < (unsigned long long)kStampRecords) {                                               \
+                unsigned *r_ = reinterpret_cast<unsigned *>(g.status) + 64 + 8 * id_;                    \
+                for (int q_ = 0; q_ < 5; ++q_) r_[q_] = st_rec[q_];                                      \
+                r_[5] = (unsigned)(t_ - st_first); r_[6] = blockIdx.x | (blockIdx.y << 16); r_[7] = st_real; \
+            }                                                                                            \
         }                                                                                                \
     } while (0)
+#define STAMP_VAL(v) do { st_real = (unsigned)(v); } while (0)
 #define STAMP_SYNC() __syncthreads()        /* so that a phase's time is the workgroup's, not thread 0's */
 #define STAMP_COUNT(k, v)                                                                                \
     do {                                                                                                 \
@@ -41,6 +51,7 @@
 #define STAMP_SYNC()
 #define STAMP_COUNT(k, v)
 #define STAMP_WAVE_COUNT(k, v)
+#define STAMP_VAL(v)
 #endif
 
 // Diagnostic build (-DSLAM_STAMPS_ICP, never shipped; not together with the grid kernels' SLAM_STAMPS: same counters): thread 0 of every pair adds the shader-clock cycles
