@@ -2221,12 +2221,15 @@ constexpr int kWedgeLenBins = 64;
 constexpr int kWedgeThreads = 512;
 constexpr int kWedgeSlots = 4;                        // rays per lane and pass
 constexpr int kWedgeCells = 37888;                    // 16-bit window cells (74 KiB): two workgroups per CU
+constexpr int kWedgePartMin = kWedgeThreads * kWedgeSlots;   // rays per part of a unit (the scratch is sized for it)
 
 struct WedgeScratch {
     uint32_t *ends;            // [rays] end cell, x | y << 16
     uint32_t *orgs;            // [scans] origin cell
     unsigned short *list;      // [rays] ray numbers inside their group, sorted by (class, length descending)
     int *offs;                 // [groups][kWedgeClasses + 1] class boundaries in the group's list
+    uint32_t *cost;            // [groups][kWedgeClasses] cells the class's rays pass (from the length bins: to +-8 cells a ray)
+    uint32_t *order;           // [groups * kWedgeClasses] units (group * kWedgeClasses + class), the most cells first
 };
 
 __device__ __forceinline__ int wedge_class(const Ray &r, int ddx, int ddy)
@@ -2309,6 +2312,13 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
         int v[kBinsPerThread], sum = 0;
 #pragma unroll
         for (int u = 0; u < kBinsPerThread; ++u) { v[u] = hist[tid * kBinsPerThread + u]; sum += v[u]; }
+        {
+            // cells a class's rays pass, from its length bins (16 cells wide): what k_wedge_order sorts the units by.  One bin
+            // per thread and kWedgeLenBins = 64 bins per class: a class is a wave.
+            static_assert(kBinsPerThread == 1 && kWedgeLenBins == kWave, "a class's bins are one wave");
+            const unsigned c = wave_sum_u32((unsigned)v[0] * (unsigned)((kWedgeLenBins - 1 - lane) * 16 + 8));
+            if (lane == 0) ws.cost[group * kWedgeClasses + wave] = c;
+        }
         int inc = sum;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { const int t = __shfl_up(inc, off, kWave); if (lane >= off) inc += t; }
@@ -2338,6 +2348,50 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
     }
 }
 
+// The work of a launch in the order k_wedge_cast takes it: a (group, class) unit is cut into PARTS of at most `part_rays` rays
+// of its length-sorted list, and the parts are sorted by decreasing work; workgroup b casts part order[1 + b] and the
+// hardware starts workgroups in index order, so the longest parts start first.  Before (stamps, round 4: 1 008 units on 512
+// workgroup slots) unit lifetimes ranged to 2.7 x the mean and the longest unit alone lasted 400 of the launch's 480 us.
+// Counting sort by the logarithm of a part's share of its unit's cost (256 buckets, order inside a bucket arbitrary).
+// order[0]: parts listed; an entry is unit | part << 20.
+__global__ void __launch_bounds__(1024) k_wedge_order(WedgeScratch ws, int units, int part_rays)
+{
+    __shared__ int hist[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    auto parts_of = [&](int u) -> int {
+        const int g = u / kWedgeClasses, c = u - g * kWedgeClasses;
+        const int nr = ws.offs[(size_t)g * (kWedgeClasses + 1) + c + 1] - ws.offs[(size_t)g * (kWedgeClasses + 1) + c];
+        return (nr + part_rays - 1) / part_rays;                      // (a class without rays: no part)
+    };
+    auto bucket = [](uint32_t c) -> int { return 255 - min(255, (int)(__log2f((float)c + 1.0f) * 9.0f)); };   // log2 < 32: 9 per octave
+    for (int u = tid; u < units; u += blockDim.x) {
+        const int np = parts_of(u);
+        if (np > 0) atomicAdd(&hist[bucket(ws.cost[u] / (uint32_t)np)], np);
+    }
+    __syncthreads();
+    if (tid < 64) {                                                  // exclusive scan of the 256 buckets by one wave
+        int h4[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h4[k] = hist[4 * tid + k]; tot += h4[k]; }
+        int inc = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const int v = __shfl_up(inc, off, kWave); if (tid >= off) inc += v; }
+        int run = inc - tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += h4[k]; }
+        if (tid == 63) ws.order[0] = (uint32_t)inc;
+    }
+    __syncthreads();
+    for (int u = tid; u < units; u += blockDim.x) {
+        const int np = parts_of(u);
+        if (np <= 0) continue;
+        const int base = atomicAdd(&hist[bucket(ws.cost[u] / (uint32_t)np)], np);
+        for (int k = 0; k < np; ++k) ws.order[1 + base + k] = (uint32_t)u | ((uint32_t)k << 20);
+    }
+}
+
 struct WedgeRay {
     int x0, y;             // walk origin along the axis; current y (the other axis, in walk coordinates)
     int k, kend;           // next walk step that passes a cell, last such step (the path's last cell - the hit - is neither)
@@ -2345,7 +2399,7 @@ struct WedgeRay {
     double error, derr;
 };
 
-__global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedge_cast(GridDev g, WedgeScratch ws, int n, int group_size, int scans)
+__global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedge_cast(GridDev g, WedgeScratch ws, int n, int group_size, int scans, int part_rays)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *box = reinterpret_cast<int *>(smem);                          // [0] a_min [1] a_max [2] v_lo [3] v_hi [4] rows of the band
@@ -2354,13 +2408,17 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
     lds_guard_fill(guard);
     STAMP_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kWedgeThreads >> 6;
-    const int cls = blockIdx.x;
-    const long group = blockIdx.y;
+    if (blockIdx.x >= ws.order[0]) return;                               // (the grid is sized for the largest possible number of parts)
+    const uint32_t entry = ws.order[1 + blockIdx.x];                     // the parts with the most cells first
+    const uint32_t unit = entry & 0xfffffu, part = entry >> 20;
+    const int cls = (int)(unit % kWedgeClasses);
+    const long group = unit / kWedgeClasses;
     const int groups_per_traj = (scans + group_size - 1) / group_size;
     const int l = (int)(group / groups_per_traj), s0 = (int)(group % groups_per_traj) * group_size;
     const long ray0 = ((long)l * scans + s0) * n;
-    const int lo = ws.offs[group * (kWedgeClasses + 1) + cls], hi = ws.offs[group * (kWedgeClasses + 1) + cls + 1];
-    if (lo == hi) return;
+    const int lo = ws.offs[group * (kWedgeClasses + 1) + cls] + (int)part * part_rays;
+    const int hi = min(ws.offs[group * (kWedgeClasses + 1) + cls + 1], lo + part_rays);
+    if (lo >= hi) return;
     const bool steep = (cls / kWedgeSlopes) >= 2;
     const int M = wedge_shear(cls);
     uint32_t *pass = g.pass;
@@ -2536,7 +2594,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
 
 size_t wedge_scratch_bytes(long rays, long scans, long groups)
 {
-    return (size_t)rays * 6 + (size_t)scans * 4 + (size_t)groups * (kWedgeClasses + 1) * 4 + 4096;
+    return (size_t)rays * 6 + (size_t)scans * 4 + (size_t)groups * (kWedgeClasses + 1) * 4 + (size_t)groups * kWedgeClasses * 8 + (size_t)(rays / kWedgePartMin + 1) * 4 + 4096;
 }
 
 template <class Src>
@@ -2555,6 +2613,8 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     ws.ends = reinterpret_cast<uint32_t *>(p); p += (size_t)rays * 4;
     ws.orgs = reinterpret_cast<uint32_t *>(p); p += (size_t)L * scans * 4;
     ws.offs = reinterpret_cast<int *>(p); p += (size_t)groups * (kWedgeClasses + 1) * 4;
+    ws.cost = reinterpret_cast<uint32_t *>(p); p += (size_t)groups * kWedgeClasses * 4;
+    ws.order = reinterpret_cast<uint32_t *>(p); p += ((size_t)groups * kWedgeClasses + (size_t)rays / kWedgePartMin + 1) * 4;
     ws.list = reinterpret_cast<unsigned short *>(p);
     if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
     const size_t lds_a = win_sc_bytes(G) + (size_t)(kWedgeClasses * kWedgeLenBins + 16) * 4 + (size_t)G * n * 2;
@@ -2563,7 +2623,12 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     if (e == hipSuccess) e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_wedge_cast), (int)lds_b);
     if (e != hipSuccess) return e;
     SLAM_LAUNCH((k_wedge_sort<Src>), dim3(groups_per_traj, L), dim3(1024), lds_a, s, g, src, ws, G);
-    SLAM_LAUNCH(k_wedge_cast, dim3(kWedgeClasses, (unsigned)groups), dim3(kWedgeThreads), lds_b, s, g, ws, n, G, scans);
+    // rays per part: what a workgroup's lanes hold in one pass.  (Smaller parts balance the launch better and cost more than they
+    // gain - every part of a class zeroes and flushes the class's bands again: 1 024 rays 0.533 ms, 512 rays 0.667 ms against 0.516.)
+    const int part_rays = kWedgeThreads * kWedgeSlots;
+    const long max_parts = groups * kWedgeClasses + rays / part_rays;      // (every unit's last part may be short)
+    SLAM_LAUNCH(k_wedge_order, dim3(1), dim3(1024), 0, s, ws, (int)(groups * kWedgeClasses), part_rays);
+    SLAM_LAUNCH(k_wedge_cast, dim3((unsigned)max_parts), dim3(kWedgeThreads), lds_b, s, g, ws, n, G, scans, part_rays);
     return hipGetLastError();
 }
 
