@@ -127,18 +127,33 @@ __global__ void __launch_bounds__(256) k_grid_update(GridDev g, const double *__
                                                      const double *__restrict__ cx, const double *__restrict__ cy, int n,
                                                      const int32_t *__restrict__ gob)
 {
+    __shared__ int first_bad;
     const int b = blockIdx.x;
     const int gi = gob ? gob[b] : 0;
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
     int cbad = 0;                                                    // the origin is the same for every beam;
     const int pcx = to_cell(cx[b], g.scale, g.off_x, cbad);          // :35  a bad origin only raises if some
     const int pcy = to_cell(cy[b], g.scale, g.off_y, cbad);          // :36  beam is actually cast
+    // the scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before it have been
+    // applied when the exception leaves update(), and the error is that beam's): find it before anything is cast
+    if (threadIdx.x == 0) first_bad = INT_MAX;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = ox[(size_t)b * n + i], y = oy[(size_t)b * n + i];
+        if (fabs(x) == INFINITY) continue;                           // mapping.py:30: only ox is tested
+        int bad = cbad;
+        (void)to_cell(x, g.scale, g.off_x, bad);
+        (void)to_cell(y, g.scale, g.off_y, bad);
+        if (bad) atomicMin(&first_bad, i);
+    }
+    __syncthreads();
+    const int stop = first_bad;
     for (int base = 0; base < n; base += blockDim.x) {
         int i = base + threadIdx.x;
         int bad = 0;
         bool first_pending = false;
         unsigned nvis = 0;
-        if (i < n) {
+        if (i < n && i <= stop) {
             double x = ox[(size_t)b * n + i], y = oy[(size_t)b * n + i];
             if (!(fabs(x) == INFINITY)) {                            // mapping.py:30: only ox is tested
                 int pox = to_cell(x, g.scale, g.off_x, bad);        // :33
@@ -160,6 +175,7 @@ __global__ void __launch_bounds__(256) k_grid_update_replay(GridDev g, const flo
                                                             const double *__restrict__ poses, int n_scan, int n,
                                                             const int32_t *__restrict__ got)
 {
+    __shared__ int first_bad;
     const int km1 = blockIdx.x, l = blockIdx.y;
     const int gi = got ? got[l] : 0;
     uint32_t *pass = g.pass + (size_t)gi * g.xw * g.yw, *hit = g.hit + (size_t)gi * g.xw * g.yw;
@@ -170,17 +186,35 @@ __global__ void __launch_bounds__(256) k_grid_update_replay(GridDev g, const flo
     int cbad = 0;
     const int pcx = to_cell(px, g.scale, g.off_x, cbad);
     const int pcy = to_cell(py, g.scale, g.off_y, cbad);
+    auto world = [&](int i, double &x, double &y) {
+        double rr = (double)r[i];
+        if (rr == INFINITY) rr = 30.0;                               // slam_ekf.py:119
+        double lx = cos_t[i] * rr, ly = sin_t[i] * rr;               // :122
+        x = c * lx + (-s) * ly + px * 1.0;                           // u2T(pose).dot(pc), :89
+        y = s * lx + c * ly + py * 1.0;
+    };
+    // (the scan stops at its first beam int() would raise on, see k_grid_update)
+    if (threadIdx.x == 0) first_bad = INT_MAX;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double x, y;
+        world(i, x, y);
+        if (fabs(x) == INFINITY) continue;
+        int bad = cbad;
+        (void)to_cell(x, g.scale, g.off_x, bad);
+        (void)to_cell(y, g.scale, g.off_y, bad);
+        if (bad) atomicMin(&first_bad, i);
+    }
+    __syncthreads();
+    const int stop = first_bad;
     for (int base = 0; base < n; base += blockDim.x) {
         int i = base + threadIdx.x;
         int bad = 0;
         bool first_pending = false;
         unsigned nvis = 0;
-        if (i < n) {
-            double rr = (double)r[i];
-            if (rr == INFINITY) rr = 30.0;                           // slam_ekf.py:119
-            double lx = cos_t[i] * rr, ly = sin_t[i] * rr;           // :122
-            double x = c * lx + (-s) * ly + px * 1.0;                // u2T(pose).dot(pc), :89
-            double y = s * lx + c * ly + py * 1.0;
+        if (i < n && i <= stop) {
+            double x, y;
+            world(i, x, y);
             if (!(fabs(x) == INFINITY)) {
                 int pox = to_cell(x, g.scale, g.off_x, bad);
                 int poy = to_cell(y, g.scale, g.off_y, bad);
@@ -1886,11 +1920,22 @@ __global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratc
     const int groups_per_traj = (scans + group_size - 1) / group_size;
     const int group = l * groups_per_traj + s / group_size;
     uint32_t *pass = g.pass, *hit = g.hit;       // single shared map (the launcher guarantees it)
+    __shared__ int first_bad;
     if (threadIdx.x == 0) {
         src.scan_const(l, s, g, sc);
         box[0] = box[1] = INT_MAX; box[2] = box[3] = INT_MIN;
+        first_bad = INT_MAX;
     }
     __syncthreads();
+    // the scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before it have been
+    // applied when the exception leaves update(), and the error is that beam's): find it before anything is recorded or cast
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int pox, poy, b2 = 0;
+        (void)src.ray(l, s, i, sc, g, pox, poy, b2);
+        if (b2) atomicMin(&first_bad, i);
+    }
+    __syncthreads();
+    const int stop = first_bad;
     unsigned nvis = 0;
     int bad = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1899,7 +1944,7 @@ __global__ void __launch_bounds__(256) k_ray_bits(GridDev g, Src src, TileScratc
         rec.flags = 0; rec.x0 = rec.y0 = rec.dx = rec.yend = 0; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
         int pox, poy, b2 = 0;
         Ray ry;
-        const bool valid = src.ray(l, s, i, sc, g, pox, poy, b2) && ray_setup(sc.pcx, sc.pcy, pox, poy, ry);
+        const bool valid = i <= stop && src.ray(l, s, i, sc, g, pox, poy, b2) && ray_setup(sc.pcx, sc.pcy, pox, poy, ry);
         // the common ray: recorded, and both ends (hence every cell) inside the map.  Only the walk's
         // decisions are needed - one bit per step - so the loop is the error recurrence alone
         // (bresenham.py:51-55), all lanes at the same step; the path's last cell is the endpoint cell
@@ -2252,8 +2297,8 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ScanConst *sc = reinterpret_cast<ScanConst *>(smem);                                   // [group_size]
     int *hist = reinterpret_cast<int *>(smem + win_sc_bytes(group_size));                  // [kWedgeClasses * kWedgeLenBins]
-    int *wsum = hist + kWedgeClasses * kWedgeLenBins;                                       // [16] cross-wave scan
-    unsigned short *keys = reinterpret_cast<unsigned short *>(wsum + 16);                   // [group_size * n]
+    int *wsum = hist + kWedgeClasses * kWedgeLenBins;                                       // [64] cross-wave scan (16 used); before it: every scan's first bad beam
+    unsigned short *keys = reinterpret_cast<unsigned short *>(wsum + kWinMaxGroup);         // [group_size * n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = blockIdx.y, n = src.n, scans = src.scans_per_traj();
     const int groups_per_traj = (scans + group_size - 1) / group_size;
@@ -2266,15 +2311,26 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
         ws.orgs[(long)l * scans + s0 + tid] = (uint32_t)(sc[tid].pcx & 0xffff) | ((uint32_t)(sc[tid].pcy & 0xffff) << 16);
     }
     for (int k = tid; k < kWedgeClasses * kWedgeLenBins; k += blockDim.x) hist[k] = 0;
+    int *fb = wsum;                                                  // [cnt <= 64 ints, ahead of the scan that uses wsum] every scan's first bad beam
+    if (tid < kWinMaxGroup) fb[tid] = INT_MAX;
     __syncthreads();
     const int nrays = cnt * n;
+    // every scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before it have been
+    // applied when the exception leaves update(), and the error is that beam's): find it before any hit or count is added
+    for (int r = tid; r < nrays; r += blockDim.x) {
+        const int s = r / n, i = r - s * n;
+        int pox, poy, b2 = 0;
+        (void)src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2);
+        if (b2) atomicMin(&fb[s], i);
+    }
+    __syncthreads();
     unsigned nvis = 0;
     int bad = 0;
     for (int r = tid; r < nrays; r += blockDim.x) {
         const int s = r / n, i = r - s * n;
         int pox, poy, b2 = 0;
         Ray ry;
-        const bool valid = src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2) && ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry);
+        const bool valid = i <= fb[s] && src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2) && ray_setup(sc[s].pcx, sc[s].pcy, pox, poy, ry);
         const bool plain = valid && (unsigned)sc[s].pcx < (unsigned)g.xw && (unsigned)sc[s].pcy < (unsigned)g.yw &&
                            (unsigned)pox < (unsigned)g.xw && (unsigned)poy < (unsigned)g.yw;
         unsigned short key = 0xffffu;
@@ -2617,7 +2673,7 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     ws.order = reinterpret_cast<uint32_t *>(p); p += ((size_t)groups * kWedgeClasses + (size_t)rays / kWedgePartMin + 1) * 4;
     ws.list = reinterpret_cast<unsigned short *>(p);
     if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
-    const size_t lds_a = win_sc_bytes(G) + (size_t)(kWedgeClasses * kWedgeLenBins + 16) * 4 + (size_t)G * n * 2;
+    const size_t lds_a = win_sc_bytes(G) + (size_t)(kWedgeClasses * kWedgeLenBins + kWinMaxGroup) * 4 + (size_t)G * n * 2;
     const size_t lds_b = 64 + (size_t)kWedgeCells * 2 + kLdsGuard;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_wedge_sort<Src>), (int)lds_a);
     if (e == hipSuccess) e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_wedge_cast), (int)lds_b);

@@ -62,6 +62,15 @@ MIXED_RW_PEAK_GBS = 4750.0
 F64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector (half the 157.3 TF FP32 vector rate)
 # f64 VALU issue: 256 CUs x 4 SIMDs, one wave64 f64 instruction per 4 cycles per SIMD at 2.4 GHz
 F64_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
+SIMD_CYCLES_PER_S = 1024 * 2.4e9
+# Issue cost of a wave instruction on one SIMD, cycles, measured with four waves per SIMD (tools/ubench_issue.hip,
+# profiles/r04_ubench_issue.txt): every float64 instruction incl. compares and min / max 4.2; DPP moves, conversions, 32-bit
+# integer multiplies 4.2-4.3; v_rcp_f32 and the like 8.3; float64 rcp / rsq / sqrt twice that; plain 32-bit ones 2.35
+ISSUE_COST = {"f64": 4.2, "quarter": 4.25, "trans_f32": 8.3, "trans_f64": 16.6, "simple": 2.35}
+# ds_add_u32 without return, 64 lanes, 16 waves per CU, every lane walking a line through a 72 KiB window of 16-bit counters
+# (the address pattern of the ray casts' walk): 5.95 adds per cycle per CU = 3.68e12 /s on 256 CUs; random dwords 5.56,
+# conflict-free 11.1 (tools/ubench_issue.hip part 2, profiles/r04_ubench_issue.txt)
+LDS_ATOMIC_PEAK = 3.68e12
 AMIN, AMAX = -3.14159, 3.14159
 
 CONFIGS = {
@@ -193,14 +202,20 @@ def cpu_baseline_particles(wl, args, budget_s):
 
 
 def source_hash():
-    """SHA-256 over the kernel sources of the library in this tree (csrc/*.hip, *.h), 16 hex digits: tools/summarize_profiles.py
-    stamps profiles/pmc_traffic.json with it, and a roofline built on PMC figures of OTHER sources says so (stale_pmc)."""
+    """SHA-256 over the kernel sources of the library in this tree (csrc/*.hip, *.h) with comments and blank lines
+    removed, 16 hex digits: tools/summarize_profiles.py stamps profiles/pmc_traffic.json with it, and a roofline built on
+    PMC figures of OTHER sources says so (stale_pmc).  (A comment edit does not change the code the counters saw.)"""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h"))):
+        text = open(f, "r", encoding="utf-8", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)              # block comments
+        text = re.sub(r"//[^\n]*", "", text)                            # line comments (no string literal of the sources holds //)
+        lines = [" ".join(ln.split()) for ln in text.splitlines()]
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update("\n".join(ln for ln in lines if ln).encode())
     return h.hexdigest()[:16]
 
 
@@ -226,7 +241,7 @@ def load_pmc(config, kernel):
         for key in ("hbm_bytes_per_launch", "valu_insts_per_launch", "lds_insts_per_launch"):
             out[key] = sum(p.get(key) or 0.0 for p in parts)
         main = max(parts, key=lambda p: p.get("valu_insts_per_launch") or 0.0)          # the family's main kernel
-        for key in ("valu_busy_frac", "issue_mix", "valu_insts_per_launch_qpt3"):
+        for key in ("valu_busy_frac", "issue_mix", "issue_mix_hw", "lds_conflict_cycle_share", "valu_insts_per_launch_qpt3"):
             if main.get(key) is not None:
                 out[key] = main[key]
     else:
@@ -234,6 +249,33 @@ def load_pmc(config, kernel):
     if out and stale:
         out["stale"] = stale
     return out
+
+
+def issue_cycles(pmc, insts=None):
+    """SIMD issue cycles of one launch: the hardware's instruction-class counters (issue_mix_hw: float64 add / mul / fma,
+    float64 and float32 transcendentals, conversions) priced with the measured cost per class; classes without a counter of
+    their own - float64 compares and min / max, DPP moves and lane exchanges - enter with their STATIC share of the kernel's
+    ISA relative to its float64 arithmetic (issue_mix.static_classes, k_icp only) scaled by the counted float64 arithmetic;
+    the rest at the plain 32-bit cost.  Returns (cycles, breakdown) or (None, None)."""
+    insts = insts or pmc.get("valu_insts_per_launch")
+    hw = pmc.get("issue_mix_hw")
+    if not insts or not hw:
+        return None, None
+    scale = insts / float(pmc.get("valu_insts_per_launch") or insts)          # (another launch shape: same mix, its own count)
+    n = {"f64_arith": hw["f64_arith"] * scale, "f64_trans": hw["f64_trans"] * scale, "cvt": hw["cvt"] * scale, "trans_f32": hw["trans_f32"] * scale}
+    st = (pmc.get("issue_mix") or {}).get("static_classes")
+    if st and st.get("f64_arith"):
+        n["f64_cmp_minmax_est"] = n["f64_arith"] * st["f64_cmp_minmax"] / float(st["f64_arith"])
+        n["dpp_lane_est"] = n["f64_arith"] * st["dpp_lane"] / float(st["f64_arith"])
+    else:
+        n["f64_cmp_minmax_est"] = n["dpp_lane_est"] = 0.0
+    rest = max(insts - sum(n.values()), 0.0)
+    cyc = ((n["f64_arith"] + n["f64_cmp_minmax_est"]) * ISSUE_COST["f64"] + (n["cvt"] + n["dpp_lane_est"]) * ISSUE_COST["quarter"] +
+           n["f64_trans"] * ISSUE_COST["trans_f64"] + n["trans_f32"] * ISSUE_COST["trans_f32"] + rest * ISSUE_COST["simple"])
+    n["simple"] = rest
+    return cyc, {"instructions": n, "cycles_per_instruction": cyc / insts, "cost_cycles": ISSUE_COST,
+                 "counters": hw.get("source"), "costs": "profiles/r04_ubench_issue.txt (tools/ubench_issue.hip)",
+                 "estimated": "float64 compares / min / max and DPP / lane exchanges have no hardware counter: static share of the kernel's ISA relative to its float64 arithmetic"}
 
 
 # --------------------------------------------------------------------------------------
@@ -547,9 +589,16 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = {"wl": wl, "elapsed": elapsed, "elapsed_local": elapsed_local, "enqueue": enqueue, "fam": fam, "closing_ms": closing_ms,
-           "n_ranks": world, "dev_results": wl.collect(), "single": None, "sustained": None, "fam_note": None}
+           "n_ranks": world, "dev_results": wl.collect(), "single": None, "sustained": None, "fam_note": None,
+           "timing_mask": [dominant] if lean else ("all" if not args.no_timing else []), "instrumented": None}
     if args.no_timing:
         return res
+    if lean:
+        # the same K steps once more with events on EVERY family's dispatches (how rounds 1-2 measured `value`): the
+        # like-for-like figure for comparisons across rounds
+        e_all, _, _, _ = timed(wl, args.steps, coll=False)
+        res["instrumented"] = {"value": wl.units_per_step * args.steps / e_all, "ms_per_step": e_all / args.steps * 1e3, "timing_mask": "all",
+                               "note": "the K steps repeated with HIP events on the dispatches of every kernel family; per-GPU figure, no collective inside"}
 
     # ---- sustained: the same workload stepped on past the contract's K steps until >= --sustain-seconds have
     #      passed, with the kernels' HIP-event times kept (the driver's K steps last a few milliseconds: all lanes
@@ -618,20 +667,32 @@ def roofline_of(args, res):
     hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
     traffic = pmc.get("hbm_bytes_per_launch")
     if dom == "icp":
-        # k_icp is bound by f64 VALU issue, not by HBM: the roofline is
-        # the chip's f64 instruction issue rate, achieved = wave-level VALU instructions per launch
-        # (rocprofv3 SQ_INSTS_VALU of this same command, profiles/) / the live launch duration
+        # k_icp is bound by vector issue, not by HBM.  frac = the SIMD issue cycles of one
+        # launch / (stand-alone launch duration x 1024 SIMDs x 2.4 GHz), the cycles from the hardware's own
+        # instruction-class counters priced with measured costs (issue_cycles above); the figure that prices EVERY
+        # instruction at the float64 cost of 4 cycles stays as all_f64_pricing.
         insts = pmc.get("valu_insts_per_launch")
-        ach = insts / (alone_ms * 1e-3) if insts else None
-        roofline = {"kernel": kname, "bound": "valu_f64_issue", "achieved": ach, "peak": F64_ISSUE_PEAK, "unit": "wave-instructions/s",
-                    "frac": ach / F64_ISSUE_PEAK if ach else pmc.get("valu_busy_frac"), "traffic": traffic,
+        cyc, detail = issue_cycles(pmc)
+        if cyc is None and insts and pmc.get("issue_mix"):
+            # (PMC passes of an older tree, without the instruction-class counters: the static float64 share at 4 cycles, the rest at 2)
+            share = pmc["issue_mix"]["f64_share"]
+            cyc, detail = insts * (4.0 * share + 2.0 * (1.0 - share)), {"fallback": "static ISA mix (tools/isa_mix.py): float64 4 cycles, the rest 2; re-run tools/profile_gpu.sh for the hardware's class counters"}
+        ach = cyc / (alone_ms * 1e-3) if cyc else None
+        all64 = insts / (alone_ms * 1e-3) / F64_ISSUE_PEAK if insts else None
+        roofline = {"kernel": kname, "bound": "valu_issue", "achieved": ach, "peak": SIMD_CYCLES_PER_S, "unit": "SIMD issue cycles/s",
+                    "frac": ach / SIMD_CYCLES_PER_S if ach else None, "traffic": traffic,
+                    "issue": detail, "all_f64_pricing": {"frac": all64, "note": "SQ_INSTS_VALU x 4 cycles: an upper bound of the issue time"},
                     "valu_busy_frac_pmc": pmc.get("valu_busy_frac"), "hbm": hbm,
-                    "note": "achieved = SQ_INSTS_VALU per launch (profiles/, same command) / stand-alone launch duration measured live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per f64 wave instruction (an upper bound of the issue time: the non-f64 share of the instructions issues in 2 cycles, see issue_mix)"}
-        mix = pmc.get("issue_mix")
-        if mix and insts:
-            # the honest peak: f64 instructions hold a SIMD for 4 cycles, the others for 2 (SIMD-32); static ISA mix of the shipped kernel
-            cyc = insts * (4.0 * mix["f64_share"] + 2.0 * (1.0 - mix["f64_share"]))
-            roofline["issue_mix"] = dict(mix, issue_cycles_per_launch=cyc, frac_of_issue_cycles=cyc / (alone_ms * 1e-3 * 1024 * 2.4e9))
+                    "note": "achieved = issue cycles per launch (instruction-class counters of the committed PMC pass x measured cost per class) / stand-alone launch duration measured live"}
+    elif kname.split("+")[0] in ("k_grid_update_win", "k_wedge_sort", "k_ray_bits"):
+        # the LDS-window ray casts: every cell visit is one ds_add_u32 into the window; HBM sees the flushed windows only
+        visits_s = wl.visits / (alone_ms * 1e-3)
+        roofline = {"kernel": kname, "bound": "lds_atomic", "achieved": visits_s, "peak": LDS_ATOMIC_PEAK, "unit": "cell visits/s",
+                    "frac": visits_s / LDS_ATOMIC_PEAK, "traffic": traffic,
+                    "hbm_algorithmic": dict(hbm, note="9 B per cell visit / duration against the 8 TB/s spec: bytes the LDS window absorbs - HBM sees `traffic`"),
+                    "lds_conflict_cycle_share": pmc.get("lds_conflict_cycle_share"),
+                    "note": "achieved = in-bounds cell visits per launch / stand-alone duration of the whole launch (walk AND its set-up, sort, zero, flush phases); "
+                            "peak = ds_add_u32 rate of 256 CUs for the walk's address pattern (tools/ubench_issue.hip: 5.95 per cycle per CU with 16 waves)"}
     else:
         roofline = dict(hbm, kernel=kname, bound="hbm", traffic=traffic)
         if traffic and alone_ms:
@@ -648,24 +709,32 @@ def roofline_of(args, res):
                               "the overlapped durations include the time a kernel shares the chip with the other lanes' kernels" % len(wl.contexts())})
     if res.get("fam_note"):
         roofline["timed_families"] = res["fam_note"]
-    if len(wl.contexts()) > 1 and hasattr(wl, "family_kernels"):
-        # Several launches share the chip: what the CHIP issued over the timed region, all kernels together
-        # (instruction counts per launch from the committed PMC passes; k_icp in the launch shape this run used)
-        tot, missing = 0.0, []
+    roofline["lanes"] = 1 if single else len(wl.contexts())          # lanes the duration behind `frac` was measured at
+    if hasattr(wl, "family_kernels"):
+        # What the CHIP issued over the timed region, all kernels of all lanes together: issue cycles per launch of every
+        # family (its instruction-class counters priced as above; k_icp in the launch shape this run used) x launches /
+        # (duration of the timed region x 1024 SIMDs x 2.4 GHz) - the one figure that describes the run `value` comes from
+        tot, tot_all64, missing = 0.0, 0.0, []
         for f, (t_ms, n_l) in fam.items():
             if not n_l:
                 continue
             kk = wl.family_kernels.get(f)
             pk = load_pmc(args.config, kk) if kk else {}
-            per = pk.get("valu_insts_per_launch_qpt3") if f == "icp" and pk.get("valu_insts_per_launch_qpt3") else pk.get("valu_insts_per_launch")
-            if per is None:
+            per = pk.get("valu_insts_per_launch_qpt3") if f == "icp" and len(wl.contexts()) > 1 and pk.get("valu_insts_per_launch_qpt3") else pk.get("valu_insts_per_launch")
+            if pmc and wl.units_per_step != profiled_units and per:
+                per = per * wl.units_per_step / float(profiled_units)
+            cyc_f, _ = issue_cycles(pk, per) if per else (None, None)
+            if per is None or cyc_f is None:
                 missing.append(f)
             else:
-                tot += per * n_l
+                tot += cyc_f * n_l
+                tot_all64 += per * 4.0 * n_l
         if not missing and elapsed > 0:
-            roofline["chip_valu_issue"] = {"achieved": tot / elapsed, "peak": F64_ISSUE_PEAK, "frac": tot / elapsed / F64_ISSUE_PEAK, "unit": "wave-instructions/s",
-                                           "note": "sum over ALL kernels of SQ_INSTS_VALU per launch (profiles/) x launches in the timed region / its duration: "
-                                                   "how busy the chip's vector issue was while %d replays overlapped" % len(wl.contexts())}
+            roofline["chip"] = {"frac": tot / elapsed / SIMD_CYCLES_PER_S, "lanes": len(wl.contexts()), "unit": "share of the chip's SIMD issue cycles over the timed region",
+                                "all_f64_pricing_frac": tot_all64 / elapsed / SIMD_CYCLES_PER_S,
+                                "note": "sum over ALL kernels of issue cycles per launch (instruction-class counters, profiles/) x launches in the timed region / its duration"}
+        elif missing:
+            roofline["chip"] = {"frac": None, "missing_counters": missing}
     iters = np.asarray(wl.iters)
     if "icp" in fam and fam["icp"][1]:
         # The figure below counts the distance evaluations an EXHAUSTIVE nearest-neighbour scan would
@@ -691,7 +760,7 @@ def roofline_of(args, res):
 
 def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, workload, units_per_step, lanes, roofline, use_dist,
                   single=None, sustained=None, parity=None, cpu_baseline=None, other_configs=None, single_gpu_same_workload=None,
-                  rccl_world_size=None):
+                  rccl_world_size=None, timing_mask=None, instrumented=None):
     """The ONE JSON line (a dict) from measured numbers.  Pure: tests/test_bench_cpu.py checks the schema of the N = 1
     and N > 1 lines with made-up measurements."""
     out = {
@@ -708,6 +777,10 @@ def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, wor
                    "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
         "roofline": roofline,
     }
+    if timing_mask is not None:
+        out["timing_mask"] = timing_mask            # kernel families whose dispatches carried HIP events in the timed K steps
+    if instrumented:
+        out["instrumented"] = instrumented
     if single:
         out["single_stream"] = single
     if sustained:
@@ -732,12 +805,15 @@ def other_config_summary(args, res, roofline, parity):
     """What the default line carries of another configuration (bench.py --config <name> prints its full line)."""
     r = {"value": res["wl"].units_per_step * args.steps / res["elapsed"], "unit": "scans/s", "ms_per_step": res["elapsed"] / args.steps * 1e3,
          "steps": args.steps, "warmup": args.warmup, "lanes": len(res["wl"].contexts()), "workload": res["wl"].workload_name(),
-         "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "physical", "stale_pmc") if k in roofline},
+         "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "lanes", "physical", "hbm_algorithmic", "lds_conflict_cycle_share", "chip", "stale_pmc") if k in roofline},
          "parity": parity}
     if res["single"]:
         r["single_stream"] = res["single"]
     if res["sustained"]:
-        r["sustained"] = {k: res["sustained"][k] for k in ("value", "ms_per_step", "steps")}
+        r["sustained"] = {k: res["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")}
+    r["timing_mask"] = res.get("timing_mask")
+    if res.get("instrumented"):
+        r["instrumented"] = res["instrumented"]
     return r
 
 
@@ -827,10 +903,24 @@ def main():
         for name in ("particles", "dense"):
             a2 = config_args(args, name)
             try:
-                r2 = measure(a2, env, want_single=True, want_sustained=False)
+                r2 = measure(a2, env, want_single=True, want_sustained=True)
                 others[name] = other_config_summary(a2, r2, roofline_of(a2, r2), None if args.no_parity else r2["wl"].parity(r2["dev_results"]))
                 r2["wl"].close()
                 del r2
+                if name == "particles":
+                    # the same batch with the hypotheses' previous poses scattered (the reference has no particle filter: SURVEY.md
+                    # 8d cfg3 starts every hypothesis at one pose; a filter's particles differ): boxes of all shapes, rays that
+                    # leave a map, the general owner kernel behind the byte-window one
+                    torch.cuda.empty_cache()
+                    a3 = argparse.Namespace(**vars(a2))
+                    a3.pose_spread = 0.5
+                    r3 = measure(a3, env, want_single=True, want_sustained=False)
+                    others[name]["scattered_poses"] = {"pose_spread": 0.5, "value": r3["wl"].units_per_step * a3.steps / r3["elapsed"], "unit": "scans/s",
+                                                       "ms_per_step": r3["elapsed"] / a3.steps * 1e3, "single_stream": r3["single"],
+                                                       "parity": None if args.no_parity else r3["wl"].parity(r3["dev_results"]),
+                                                       "note": "previous poses drawn from N(0, 0.5) in x, y and heading (as tests/test_gpu_configs.py::test_config2_10000_particles does)"}
+                    r3["wl"].close()
+                    del r3
             except Exception as e:                      # the headline line must not die of a secondary configuration
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
@@ -841,7 +931,7 @@ def main():
         out = assemble_line(args, n_ranks, value, res["elapsed"] / args.steps * 1e3, res["enqueue"] / args.steps * 1e3, res["closing_ms"],
                             wl_name, units, lanes, roofline, use_dist, single=single, sustained=sustained, parity=parity, cpu_baseline=cpu,
                             other_configs=others, single_gpu_same_workload=same_workload,
-                            rccl_world_size=n_ranks if use_dist else None)
+                            rccl_world_size=n_ranks if use_dist else None, timing_mask=res.get("timing_mask"), instrumented=res.get("instrumented"))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -109,13 +109,16 @@ def test_map_state_after_a_raising_beam_equals_the_references(env, xw, live, bad
     g.close()
 
 
-def test_batched_update_stops_each_scan_at_its_first_raising_beam(env):
-    """Several scans in ONE call (the LDS-window kernel): every scan is cast up to its own first beam that int()
-    would raise on, as the reference's loop over that scan would have (mapping.py:29-36); the call reports that
-    beam's error.  (The reference's caller would not even start the scans after the offending one: those are still
-    applied here - INTEGRATION.md section 5.)"""
+@pytest.mark.parametrize("grid_mode", [0, 1, 2, 3, 4])
+def test_batched_update_stops_each_scan_at_its_first_raising_beam(env, grid_mode):
+    """Several scans in ONE call, through every ray-cast path (grid_mode 0: direct atomics, 1 / 3: LDS window, 2: recorded
+    walks + tiles, 4: direction wedges): every scan is cast up to its own first beam that int() would raise on, as the
+    reference's loop over that scan would have (mapping.py:29-36); the call reports that beam's error.  (The reference's
+    caller would not even start the scans after the offending one: those are still applied here - INTEGRATION.md section 5.)"""
     from oracle import c_oracle as co
-    slam, A, L, ctx = env
+    slam, A, L, _ = env
+    ctx = slam.Context(0)
+    ctx.set_option("grid_mode", grid_mode)
     rng = np.random.default_rng(12)
     B, n = 5, 120
     ang = np.linspace(-3.1, 3.1, n)
@@ -125,6 +128,7 @@ def test_batched_update_stops_each_scan_at_its_first_raising_beam(env):
     oy[1, 40] = np.nan
     oy[1, 77] = np.inf                                           # never reached
     ox[3, 3] = np.nan
+    ox[4, 100] = np.inf                                          # skipped, not an error (mapping.py:30 tests ox only)
     g = slam.DeviceGrid(1, 400, 400, 20.0, 10.0, 10.0, context=ctx)
     with pytest.raises(ValueError):
         g.update_host(ox, oy, cx, cy)
@@ -133,4 +137,22 @@ def test_batched_update_stops_each_scan_at_its_first_raising_beam(env):
         og.update(ox[b, :stop], oy[b, :stop], cx[b], cy[b])
     got = g.read(0, want=("pass", "hit"))
     assert np.array_equal(got["pass"], og.pass_cnt) and np.array_equal(got["hit"], og.hit_cnt) and g.visits() == og.visits
+    # the same through the replay form (raw ranges + poses): a NaN range raises at its beam
+    g.reset()
+    ranges = rng.uniform(2.0, 8.0, size=(B, n)).astype(np.float32)
+    ranges[2, 55] = np.nan
+    ranges[4, 0] = np.nan
+    poses = np.column_stack([cx, cy, rng.uniform(-1, 1, B)])
+    m = slam.Mapping.metric(400, 400, 0.05, context=ctx) if hasattr(slam.Mapping, "metric") else None
+    if m is not None:
+        with pytest.raises(ValueError):
+            m.update_scans(ranges, -3.1, 3.1, poses, None)
+        og = co.Grid(400, 400, 20.0, 10.0, 10.0)
+        from oracle import oracle_np as on
+        for b, stop in ((0, n), (1, n), (2, 55), (3, n), (4, 0)):
+            obs = on.world_points(poses[b], on.laser_to_numpy(ranges[b], -3.1, 3.1, clip_inf=True))
+            og.update(obs[0][:stop], obs[1][:stop], poses[b][0], poses[b][1])
+        p, h = m.counters()
+        assert np.array_equal(p, og.pass_cnt) and np.array_equal(h, og.hit_cnt)
     g.close()
+    ctx.close()

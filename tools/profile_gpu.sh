@@ -8,7 +8,9 @@
 #     durations include overlap)
 #  2. the same for one lane (kernels back to back: their stand-alone durations)
 #  3. --pmc passes, ONE counter group per run and nothing else enabled (the pool refuses
-#     --pmc combined with other trace domains), one lane.
+#     --pmc combined with other trace domains), one lane, particle batches in one piece: HBM traffic, cache
+#     requests, occupancy and waits, and the hardware's own count of float64 / conversion / transcendental
+#     instructions (what bench.py prices a kernel's vector issue with).
 set -u
 TAG=${1:-r02}
 CFG=${2:-replay}
@@ -21,7 +23,7 @@ case $CFG in
   replay) STEPS="--steps 48 --warmup 5"; PSTEPS="--steps 5 --warmup 1";;
   *)      STEPS="--steps 12 --warmup 3"; PSTEPS="--steps 3 --warmup 1";;
 esac
-COMMON="--config $CFG --no-cpu-baseline --no-single-stream --no-other-configs --sustain-seconds 0"
+COMMON="--config $CFG --no-cpu-baseline --no-single-stream --no-other-configs --sustain-seconds 0 --particle-chunks 1"
 # shellcheck disable=SC2086
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 "$R/bench.py" $COMMON $STEPS \
     > "$OUT/bench_default_under_rocprof.json" 2> "$OUT/trace_default.err" || { echo "kernel trace (default) failed"; tail -5 "$OUT/trace_default.err"; exit 1; }
@@ -32,7 +34,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1lane" -- py
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU"; do
     i=$((i + 1))
     # shellcheck disable=SC2086
     rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$i" -- python3 "$R/bench.py" $COMMON $PSTEPS --lanes 1 --no-parity \
@@ -42,9 +45,9 @@ done
 if [ "$CFG" = replay ]; then
     # instruction count of k_icp in the launch shape the overlapped default run uses (three queries per lane)
     # shellcheck disable=SC2086
-    rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_6" -- python3 "$R/bench.py" $COMMON $PSTEPS --lanes 1 --no-parity --icp-qpt 3 \
-        > /dev/null 2>> "$OUT/pmc.err" || { echo "pmc pass 6 failed"; tail -5 "$OUT/pmc.err"; exit 1; }
-    echo "SQ_INSTS_VALU icp_qpt=3" > "$OUT/pmc_6/counters.txt"
+    rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_7" -- python3 "$R/bench.py" $COMMON $PSTEPS --lanes 1 --no-parity --icp-qpt 3 \
+        > /dev/null 2>> "$OUT/pmc.err" || { echo "pmc pass 7 failed"; tail -5 "$OUT/pmc.err"; exit 1; }
+    echo "SQ_INSTS_VALU icp_qpt=3" > "$OUT/pmc_7/counters.txt"
 fi
 [ "$CFG" = replay ] && python3 "$R/tools/isa_mix.py" "$OUT/isa_mix.json" > /dev/null
 # the summary first (it puts this run's PMC figures under profiles/ of this copy of the tree), then the plain bench line that

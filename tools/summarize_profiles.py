@@ -101,6 +101,17 @@ def main():
                       "lds_insts_per_launch": avg("SQ_INSTS_LDS")}
         if c.get("SQ_INSTS_VALU@qpt3"):
             traffic[k]["valu_insts_per_launch_qpt3"] = avg("SQ_INSTS_VALU@qpt3")
+        if c.get("SQ_INSTS_VALU_ADD_F64") is not None and c.get("SQ_INSTS_VALU_FMA_F64") is not None:
+            # the hardware's own instruction classes (per launch): float64 add / mul / fma, float64 and float32
+            # transcendentals, conversions; SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = lanes active per instruction
+            traffic[k]["issue_mix_hw"] = {"f64_arith": (avg("SQ_INSTS_VALU_ADD_F64") or 0.0) + (avg("SQ_INSTS_VALU_MUL_F64") or 0.0) + (avg("SQ_INSTS_VALU_FMA_F64") or 0.0),
+                                          "f64_trans": avg("SQ_INSTS_VALU_TRANS_F64") or 0.0, "cvt": avg("SQ_INSTS_VALU_CVT") or 0.0,
+                                          "trans_f32": avg("SQ_INSTS_VALU_TRANS_F32") or 0.0, "int32": avg("SQ_INSTS_VALU_INT32") or 0.0,
+                                          "active_lanes_per_inst": (avg("SQ_THREAD_CYCLES_VALU") or 0.0) / max(avg("SQ_INSTS_VALU") or 1.0, 1.0),
+                                          "source": "profiles/%s_pmc_summary.txt: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, _CVT, _TRANS_F32, _INT32 per launch" % tag}
+        lds_c, lds_a = avg("SQ_LDS_BANK_CONFLICT"), avg("SQ_LDS_IDX_ACTIVE")
+        if lds_a:
+            traffic[k]["lds_conflict_cycle_share"] = lds_c / lds_a
         lines.append("%s HBM %.3f MB VALU busy %s" % (k, hbm / 1e6, "n/a" if busy is None else "%.1f %%" % (100 * busy)))
     open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
     allcfg = {}
