@@ -1375,86 +1375,136 @@ hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const
 // walked by one lane, in the reference's evaluation order:
 //   x = (x + cos(th)*tx) - sin(th)*ty;  y = (y + sin(th)*tx) + cos(th)*ty;  th = th + dyaw.
 // ---------------------------------------------------------------------------------
-// A small footprint on purpose (256 lanes, 24 KB of LDS; 1 024 lanes and 96 KB until the end of round 3): the
-// kernel is one workgroup per trajectory that other kernels' workgroups have to make room for - when replays overlap on
-// several contexts its launch waited for a CU with that much free LDS, 57 us instead of 27 from dispatch to end, and
-// its stream stood still meanwhile (four overlapping 999-pair replays: 9.2 -> 10.0 M scans/s with the small one).
-constexpr int kComposeChunk = 512;
+// A small footprint on purpose (256 lanes, 9 KB of LDS; 1 024 lanes and 96 KB until the end of round 3): the kernel is one
+// workgroup per trajectory that other kernels' workgroups have to make room for - when replays overlap on several contexts
+// its launch waited for a CU with that much free LDS, 57 us instead of 27 from dispatch to end, and its stream stood still
+// meanwhile (four overlapping 999-pair replays: 9.2 -> 10.0 M scans/s with the small one).
+//
+// Round 4: a pipeline of the four waves over chunks of 64 steps, one barrier per stage.  The two recurrences are chains of
+// dependent float64 adds that ONE lane has to walk in the reference's order, and what they cost is that lane's own
+// instruction stream (a lone wave issues an instruction every ~5 cycles: until round 4 a step cost 72 cycles, of which the
+// adds themselves are ~27).  Now wave 0 walks the heading chain of chunk c while wave 1 walks the position chains of chunk
+// c - 2, wave 2 computes delta_yaw (atan2) of chunk c + 1 and stores the positions of chunk c - 3, and wave 3 computes
+// cos / sin of chunk c - 1's headings: every wave on a SIMD of its own, every value through LDS, operands read two per
+// instruction (ds_read_b128) a batch ahead of their use, the matrices' elements loaded from memory a stage ahead.  Same
+// operations in the same order as before: results are bit-identical.
+constexpr int kComposeChunk = 64;
 constexpr int kComposeThreads = 256;
-constexpr int kComposeUnroll = 16;
+constexpr int kComposeBatch = 16;
 
-// The two serial scans are latency chains of float64 adds.  One lane walks the heading
-// chain and two lanes (x and y, same instruction stream) the position chains; operands are
-// read from LDS sixteen at a time, and the arrays are zero-padded to a multiple of 16 so the
-// unrolled bodies need no bounds checks (adding 0.0 leaves a running sum bit-identical).
 __global__ void __launch_bounds__(kComposeThreads) k_pose_compose(const double *__restrict__ T, const double *__restrict__ pose0, int n,
                                                                   double *__restrict__ poses)
 {
-    __shared__ double dyaw[kComposeChunk], thb[kComposeChunk];
-    __shared__ double add1[2][kComposeChunk], sub2[2][kComposeChunk];   // [0]: x terms, [1]: y terms
-    __shared__ double carry[3];
-    // (a latency chain on one wave: on a SIMD shared with other kernels' waves it would get every fourth issue slot)
+    __shared__ __attribute__((aligned(16))) double dyaw[3][kComposeChunk];           // delta_yaw of a chunk's steps (icp.py:185)
+    __shared__ __attribute__((aligned(16))) double thb[2][kComposeChunk];            // heading BEFORE each step
+    __shared__ __attribute__((aligned(16))) double ab[2][kComposeChunk][4];          // c tx, s ty | s tx, -(c ty)
+    __shared__ __attribute__((aligned(16))) double xo[2][2][kComposeChunk];          // [x | y] after each step
+    // (latency chains on single waves: on a SIMD shared with other kernels' waves they would get every fourth issue slot)
     __builtin_amdgcn_s_setprio(3);
-    const int l = blockIdx.x, tid = threadIdx.x;
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *Tl = T + 9 * (long)l * n;
     double *Pl = poses + 3 * (long)l * n;
-    if (tid == 0) { carry[0] = pose0[3 * l]; carry[1] = pose0[3 * l + 1]; carry[2] = pose0[3 * l + 2]; }
-    for (int base = 0; base < n; base += kComposeChunk) {
-        const int cnt = min(kComposeChunk, n - base);
-        const int cntp = (cnt + kComposeUnroll - 1) / kComposeUnroll * kComposeUnroll;
-        for (int k = tid; k < cntp; k += blockDim.x) {
-            double d = 0.0;
-            if (k < cnt) {
-                const double *t = Tl + 9 * (long)(base + k);
-                d = atan2(t[3], t[0]);                               // icp.py:185
+    const int nc = (n + kComposeChunk - 1) / kComposeChunk;
+    // chain state, in the registers of the lanes that walk the chains
+    double th = pose0[3 * l + 2];
+    double v = pose0[3 * l + (lane & 1)];                             // wave 1: lane 0 walks x, lane 1 walks y
+    // matrix elements a stage ahead: wave 2 wants T10, T00 of chunk s, wave 3 T02, T12 of chunk s - 2
+    auto load2 = [&](int chunk, int e0, int e1, double &u0, double &u1) {
+        const int k = chunk * kComposeChunk + lane;
+        const bool in = chunk >= 0 && chunk < nc && k < n;
+        u0 = in ? Tl[9 * (long)k + e0] : 0.0;
+        u1 = in ? Tl[9 * (long)k + e1] : 0.0;
+    };
+    double m0 = 0.0, m1 = 0.0;
+    if (wave == 2) load2(0, 3, 0, m0, m1);
+    if (wave == 3) load2(-2, 2, 5, m0, m1);
+    for (int s = 0; s < nc + 4; ++s) {
+        if (wave == 0) {
+            // heading chain of chunk s - 1: th_before[k] = th; th = th + dyaw[k] (icp.py:190)
+            const int c = s - 1;
+            if (c >= 0 && c < nc && lane == 0) {
+                const double2 *d2 = reinterpret_cast<const double2 *>(dyaw[c % 3]);
+                double2 *o2 = reinterpret_cast<double2 *>(thb[c & 1]);
+                double2 cur[kComposeBatch / 2], nxt[kComposeBatch / 2];
+#pragma unroll
+                for (int u = 0; u < kComposeBatch / 2; ++u) cur[u] = d2[u];
+#pragma unroll
+                for (int b0 = 0; b0 < kComposeChunk; b0 += kComposeBatch) {
+                    if (b0 + kComposeBatch < kComposeChunk) {
+#pragma unroll
+                        for (int u = 0; u < kComposeBatch / 2; ++u) nxt[u] = d2[(b0 + kComposeBatch) / 2 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kComposeBatch / 2; ++u) {
+                        double2 o;
+                        o.x = th; th = th + cur[u].x;
+                        o.y = th; th = th + cur[u].y;
+                        o2[b0 / 2 + u] = o;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kComposeBatch / 2; ++u) cur[u] = nxt[u];
+                }
             }
-            dyaw[k] = d;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double th = carry[2];
-            for (int k = 0; k < cntp; k += kComposeUnroll) {
-                double d[kComposeUnroll], o[kComposeUnroll];
+        } else if (wave == 1) {
+            // position chains of chunk s - 3, in the reference's evaluation order (icp.py:188-189):
+            //   x = (x + c tx) - s ty;   y = (y + s tx) + c ty = (y + s tx) - (-(c ty))
+            const int c = s - 3;
+            if (c >= 0 && c < nc && lane < 2) {
+                const double2 *p2 = reinterpret_cast<const double2 *>(&ab[c & 1][0][0]) + lane;     // step k: p2[2 k]
+                double2 *o2 = reinterpret_cast<double2 *>(xo[c & 1][lane]);
+                double2 cur[kComposeBatch], nxt[kComposeBatch];
 #pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) d[u] = dyaw[k + u];
+                for (int u = 0; u < kComposeBatch; ++u) cur[u] = p2[2 * u];
 #pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) { o[u] = th; th = th + d[u]; }   // :190
+                for (int b0 = 0; b0 < kComposeChunk; b0 += kComposeBatch) {
+                    if (b0 + kComposeBatch < kComposeChunk) {
 #pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) thb[k + u] = o[u];
+                        for (int u = 0; u < kComposeBatch; ++u) nxt[u] = p2[2 * (b0 + kComposeBatch + u)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kComposeBatch; u += 2) {
+                        double2 o;
+                        v = (v + cur[u].x) - cur[u].y;
+                        o.x = v;
+                        v = (v + cur[u + 1].x) - cur[u + 1].y;
+                        o.y = v;
+                        o2[(b0 + u) / 2] = o;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kComposeBatch; ++u) cur[u] = nxt[u];
+                }
             }
-            carry[2] = th;
-        }
-        __syncthreads();
-        for (int k = tid; k < cntp; k += blockDim.x) {
-            double a_ = 0, b_ = 0, c_ = 0, d_ = 0;
-            if (k < cnt) {
-                const double *t = Tl + 9 * (long)(base + k);
-                double c = cos(thb[k]), s = sin(thb[k]);
-                a_ = c * t[2]; b_ = s * t[5]; c_ = s * t[2]; d_ = c * t[5];
+        } else if (wave == 2) {
+            // delta_yaw of chunk s (this stage's matrix elements were loaded a stage ago; the next chunk's are requested
+            // first), then the finished positions of chunk s - 4
+            double n0, n1;
+            load2(s + 1, 3, 0, n0, n1);
+            if (s < nc) dyaw[s % 3][lane] = (s * kComposeChunk + lane < n) ? atan2(m0, m1) : 0.0;   // icp.py:185
+            m0 = n0; m1 = n1;
+            const int c = s - 4, k = c * kComposeChunk + lane;
+            if (c >= 0 && k < n) {
+                Pl[3 * (long)k] = xo[c & 1][0][lane];
+                Pl[3 * (long)k + 1] = xo[c & 1][1][lane];
             }
-            // x = (x + c*tx) - s*ty ;  y = (y + s*tx) + c*ty = (y + s*tx) - (-(c*ty))   (:188-189)
-            add1[0][k] = a_; sub2[0][k] = b_; add1[1][k] = c_; sub2[1][k] = -d_;
-        }
-        __syncthreads();
-        if (tid < 2) {
-            const double *p = add1[tid], *q = sub2[tid];
-            double *o = add1[tid];
-            double v = carry[tid];
-            for (int k = 0; k < cntp; k += kComposeUnroll) {
-                double u1[kComposeUnroll], u2[kComposeUnroll];
-#pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) { u1[u] = p[k + u]; u2[u] = q[k + u]; }
-#pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) { v = (v + u1[u]) - u2[u]; u1[u] = v; }
-#pragma unroll
-                for (int u = 0; u < kComposeUnroll; ++u) o[k + u] = u1[u];
+        } else {
+            // cos / sin of the heading before each step of chunk s - 2, the four products the position chains add, and the
+            // heading after the step
+            double n0, n1;
+            load2(s - 1, 2, 5, n0, n1);
+            const int c = s - 2, k = c * kComposeChunk + lane;
+            if (c >= 0 && c < nc) {
+                double a_ = 0.0, b_ = 0.0, c_ = 0.0, d_ = 0.0;
+                if (k < n) {
+                    const double h = thb[c & 1][lane];
+                    const double cs = cos(h), sn = sin(h);
+                    a_ = cs * m0; b_ = sn * m1; c_ = sn * m0; d_ = cs * m1;
+                    Pl[3 * (long)k + 2] = h + dyaw[c % 3][lane];     // icp.py:190
+                }
+                double2 *q = reinterpret_cast<double2 *>(&ab[c & 1][lane][0]);
+                q[0] = make_double2(a_, b_);
+                q[1] = make_double2(c_, -d_);
             }
-            carry[tid] = v;
-        }
-        __syncthreads();
-        for (int k = tid; k < cnt; k += blockDim.x) {
-            double *p = Pl + 3 * (long)(base + k);
-            p[0] = add1[0][k]; p[1] = add1[1][k]; p[2] = thb[k] + dyaw[k];
+            m0 = n0; m1 = n1;
         }
         __syncthreads();
     }
