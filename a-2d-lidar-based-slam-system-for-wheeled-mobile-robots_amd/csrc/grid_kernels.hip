@@ -645,9 +645,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
 
     // pass 1: bounding box of everything the group's rays can touch, and of the four quadrants' rays
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN, bad = 0;
-    int qb[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { qb[q][0] = qb[q][1] = INT_MAX; qb[q][2] = qb[q][3] = INT_MIN; }
     for (int r = tid; r < nrays; r += blockDim.x) {
         int s = r / n, i = r - s * n, pox, poy, len = 0, b2 = 0, quad = 0;
         const bool valid = src.ray(l, s0 + s, i, sc[s], g, pox, poy, b2);
@@ -657,13 +654,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
             bx0 = min(bx0, rx0); bx1 = max(bx1, rx1);
             by0 = min(by0, ry0); by1 = max(by1, ry1);
             len = max(abs(pox - sc[s].pcx), abs(poy - sc[s].pcy));
-            if (quads) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    qb[q][0] = quad == q ? min(qb[q][0], rx0) : qb[q][0]; qb[q][1] = quad == q ? min(qb[q][1], ry0) : qb[q][1];
-                    qb[q][2] = quad == q ? max(qb[q][2], rx1) : qb[q][2]; qb[q][3] = quad == q ? max(qb[q][3], ry1) : qb[q][3];
-                }
-            }
         }
         // a scan stops at its first beam that Python's int() would raise on (mapping.py:29-36: the beams before
         // it have been applied when the exception leaves update(), and the error is that beam's)
@@ -684,15 +674,6 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     if (lane == 0 && bx0 <= bx1) {
         atomicMin(&box[0], bx0); atomicMin(&box[1], by0); atomicMax(&box[2], bx1); atomicMax(&box[3], by1);
     }
-    if (quads) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int a0 = wave_min_i32(qb[q][0]), a1 = wave_min_i32(qb[q][1]), a2 = wave_max_i32(qb[q][2]), a3 = wave_max_i32(qb[q][3]);
-            if (lane == 0 && a0 <= a2) {
-                atomicMin(&box[16 + 4 * q], a0); atomicMin(&box[17 + 4 * q], a1); atomicMax(&box[18 + 4 * q], a2); atomicMax(&box[19 + 4 * q], a3);
-            }
-        }
-    }
     __syncthreads();
     if (tid < cnt && fb[tid] != INT_MAX) {                           // the first bad beam's own error (NaN or overflow)
         int pox, poy, b2 = 0;
@@ -702,6 +683,16 @@ __global__ void __launch_bounds__(1024) k_grid_update_win(GridDev g, Src src, in
     int *phw = box + kWinPhase;                                      // [4][8] window of a phase: x0, y0, W, H, covers
     int *phq = box + kWinPhase + 32;                                 // [4] phase of a quadrant's rays (-1: not this workgroup's)
     int *seg = box + kWinPhase + 36;                                 // [5] boundaries of the phases in the sorted order
+    if (tid == 0 && quads && box[0] <= box[2]) {
+        // A quadrant's rays lie between the group's origins and the edges of its bounding box on the quadrant's side (every ray
+        // lies in the box of its two ends): the box of quadrant q from the box of everything and the extremes of the origins
+        int ox0 = INT_MAX, oy0 = INT_MAX, ox1 = INT_MIN, oy1 = INT_MIN;
+        for (int k = 0; k < cnt; ++k) { ox0 = min(ox0, sc[k].pcx); ox1 = max(ox1, sc[k].pcx); oy0 = min(oy0, sc[k].pcy); oy1 = max(oy1, sc[k].pcy); }
+        for (int q = 0; q < 4; ++q) {
+            box[16 + 4 * q] = (q & 1) ? max(ox0, box[0]) : box[0]; box[18 + 4 * q] = (q & 1) ? box[2] : min(ox1, box[2]);
+            box[17 + 4 * q] = (q & 2) ? max(oy0, box[1]) : box[1]; box[19 + 4 * q] = (q & 2) ? box[3] : min(oy1, box[3]);
+        }
+    }
     if (tid == 0 && quads) {
         // union of the quadrants in mask -> clamped box; false: empty
         auto box_of = [&](unsigned mask, int *o) -> bool {
