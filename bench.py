@@ -103,6 +103,7 @@ def parse():
     ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window; direction wedges on maps much larger than a window), 0: direct global atomics, 2: recorded walks + tiles, 3: window, 4: wedges")
     ap.add_argument("--grid-group", type=int, default=-1,
                     help="scans per ray-cast workgroup (0: the library's choice; default: 12 when replays overlap, else 0)")
+    ap.add_argument("--grid-split", type=int, default=None, choices=[-1, 0, 1], help="window ray cast: two workgroups per group of scans (default: the library's choice for one lane, off when replays overlap)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
     ap.add_argument("--icp-qpt", type=int, default=None, help="scan-matching queries per lane (default: 3 with several lanes, else the library's choice by batch size)")
     ap.add_argument("--lanes", type=int, default=None, help="contexts (stream sets) the replays alternate between")
@@ -308,7 +309,7 @@ class ReplayWorkload:
             ln.dr.ctx.set_option("pipeline", args.pipeline)
             # several replays share the chip: one workgroup per group of scans (least total work); a lone replay leaves
             # the choice to the library (two, one per direction half: shortest launch)
-            ln.dr.ctx.set_option("grid_split", 0 if n_lanes > 1 else -1)
+            ln.dr.ctx.set_option("grid_split", args.grid_split if args.grid_split is not None else (0 if n_lanes > 1 else -1))
             # several replays share the chip: three queries per lane (fewest instructions); a lone
             # replay leaves the choice to the library (two: shortest launch)
             ln.dr.ctx.set_option("icp_qpt", args.icp_qpt if args.icp_qpt is not None else int(os.environ.get("SLAM_BENCH_QPT", 3 if n_lanes > 1 else 0)))

@@ -81,3 +81,45 @@ def test_json_line_schema_single_and_multi_gpu():
     assert many["n_gpus"] == 8 and many["rccl_world_size"] == 8 and many["config"]["workload"].startswith("configs[3]")
     assert abs(many["scaling_efficiency_same_workload"] - 6.8e7 / (8 * 9.0e6)) < 1e-12
     assert "all_gather" in many["config"]["parallelism"] and many["single_stream"]["kernel_ms_per_launch"]["icp"] == 0.6
+
+
+def test_issue_cycles_prices_counted_instruction_classes():
+    """bench.issue_cycles: a launch's SIMD issue cycles from the hardware's instruction-class counters and the measured cost
+    per class; classes without a counter (float64 compares / min / max, DPP and lane exchanges) enter with their static
+    share relative to the counted float64 arithmetic; everything else at the plain 32-bit cost."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pmc = {"valu_insts_per_launch": 1000.0,
+           "issue_mix_hw": {"f64_arith": 300.0, "f64_trans": 10.0, "cvt": 20.0, "trans_f32": 5.0, "int32": 100.0, "source": "x"},
+           "issue_mix": {"static_classes": {"f64_arith": 3000, "f64_cmp_minmax": 1500, "dpp_lane": 600}}}
+    cyc, detail = bench.issue_cycles(pmc)
+    c = bench.ISSUE_COST
+    n = detail["instructions"]
+    assert n["f64_cmp_minmax_est"] == 150.0 and n["dpp_lane_est"] == 60.0 and abs(n["simple"] - (1000 - 300 - 10 - 20 - 5 - 150 - 60)) < 1e-9
+    want = (300 + 150) * c["f64"] + (20 + 60) * c["quarter"] + 10 * c["trans_f64"] + 5 * c["trans_f32"] + n["simple"] * c["simple"]
+    assert abs(cyc - want) < 1e-9 and abs(detail["cycles_per_instruction"] - want / 1000.0) < 1e-12
+    # another launch shape of the same kernel (its own instruction count): the same mix, scaled
+    cyc2, _ = bench.issue_cycles(pmc, 2000.0)
+    assert abs(cyc2 - 2.0 * want) < 1e-6
+    # without the class counters there is nothing to price
+    assert bench.issue_cycles({"valu_insts_per_launch": 1000.0}) == (None, None)
+    # a kernel without static classes: counted classes only
+    cyc3, d3 = bench.issue_cycles({"valu_insts_per_launch": 100.0, "issue_mix_hw": {"f64_arith": 10.0, "f64_trans": 0.0, "cvt": 0.0, "trans_f32": 0.0}})
+    assert abs(cyc3 - (10 * c["f64"] + 90 * c["simple"])) < 1e-9 and d3["instructions"]["f64_cmp_minmax_est"] == 0.0
+
+
+def test_source_stamp_ignores_comments_and_blank_lines(tmp_path, monkeypatch):
+    """The stamp that ties profiles/pmc_traffic.json to the kernel sources hashes code only: a comment or blank-line edit must
+    not mark the committed PMC figures stale, a code edit must."""
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = tmp_path / bench.PKG / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "a.hip").write_text("// header\nint f(int x)\n{\n    return x + 1;   // add one\n}\n")
+    (csrc / "b.h").write_text("/* block\n   comment */\n#pragma once\nconstexpr int k = 3;\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h0 = bench.source_hash()
+    (csrc / "a.hip").write_text("// another header, longer\n\n\nint f(int x)\n{\n    return x + 1;       /* add one */\n}\n\n")
+    assert bench.source_hash() == h0
+    (csrc / "a.hip").write_text("int f(int x)\n{\n    return x + 2;\n}\n")
+    assert bench.source_hash() != h0
