@@ -21,6 +21,7 @@ export TMPDIR=/tmp
 cd /tmp || exit 1
 case $CFG in
   replay) STEPS="--steps 48 --warmup 5"; PSTEPS="--steps 5 --warmup 1";;
+  particles) STEPS="--steps 12 --warmup 3"; PSTEPS="--steps 6 --warmup 6";;   # (PMC figures from the later half of the launches: settled maps)
   *)      STEPS="--steps 12 --warmup 3"; PSTEPS="--steps 3 --warmup 1";;
 esac
 COMMON="--config $CFG --no-cpu-baseline --no-single-stream --no-other-configs --sustain-seconds 0 --particle-chunks 1"

@@ -59,7 +59,7 @@ def main():
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    lines = ["# rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --config %s --no-cpu-baseline --lanes 1 (few steps)" % cfg,
+    lines = ["# rocprofv3 --pmc passes (separate runs, --pmc only) of: python3 bench.py --config %s --no-cpu-baseline --lanes 1 (few steps%s)" % (cfg, "; the later half of every kernel's launches: maps that have seen a few scans" if cfg == "particles" else ""),
              "# per-launch averages; FETCH_SIZE / WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes)", ""]
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
@@ -68,11 +68,19 @@ def main():
         lines.append("## --pmc " + grp)
         local = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
-            for row in csv.DictReader(open(f)):
+            rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id") or 0))
+            for row in rows:
                 k = short(row["Kernel_Name"])
                 if not k.startswith("k_"):
                     continue
                 local[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if cfg == "particles":
+            # the particle maps persist across steps: a map's first scans find every cell fresh (pmap written everywhere);
+            # the benchmark's hundreds of steps run in the settled state, which the LATER HALF of a pass's launches show
+            for k in local:
+                for c in local[k]:
+                    v = local[k][c]
+                    local[k][c] = v[len(v) // 2:]
         for k in sorted(local):
             lines.append("%s %s" % (k, {c: "%.4g (n=%d)" % (sum(v) / len(v), len(v)) for c, v in sorted(local[k].items())}))
             for c, v in local[k].items():

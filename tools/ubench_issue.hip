@@ -6,6 +6,7 @@
 // Part 1: per class, a loop of 256 independent instructions (8 rotating destinations) run by W waves per SIMD on every CU;
 //         cycles per wave-instruction per SIMD = elapsed x clock / (instructions per wave x waves per SIMD).  The clock is
 //         taken from s_memtime against s_memrealtime (100 MHz) inside the kernel.
+// Part 3: a chain of dependent v_add_f64 in one wave alone (latency per step of a serial recurrence: k_pose_compose).
 // Part 2: ds_add_u32 (no return) from 64 lanes into a 36 864-cell (72 KiB) window of 16-bit counters, two per dword, as
 //         k_grid_update_win / k_wedge_cast issue it: (a) every lane a random dword, (b) every lane walks its own line
 //         through the window (the address pattern of the walk), (c) conflict-free (lane-linear); 1-16 waves per CU.
@@ -21,8 +22,10 @@
         if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
     } while (0)
 
-constexpr int kRep = 32;        // instruction groups of 8 per loop trip
+constexpr int kRep = 32;        // instruction groups of 8 per loop trip (written out: R32)
 constexpr int kTrips = 200;
+#define R4(x) x x x x
+#define R32(x) R4(x) R4(x) R4(x) R4(x) R4(x) R4(x) R4(x) R4(x)
 
 #define GROUP8(op)                                                                                                               \
     asm volatile(op(%0) op(%1) op(%2) op(%3) op(%4) op(%5) op(%6) op(%7) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc")
@@ -39,14 +42,11 @@ __global__ void __launch_bounds__(256) k_issue_f64(double *out, unsigned long lo
     double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < kTrips; ++t) {
-#pragma unroll
-        for (int r = 0; r < kRep; ++r) {
-            if (KIND == 0) GROUP8(OP_ADD_F64);
-            if (KIND == 1) GROUP8(OP_MUL_F64);
-            if (KIND == 2) GROUP8(OP_FMA_F64);
-            if (KIND == 3) GROUP8(OP_MIN_F64);
-            if (KIND == 4) GROUP8(OP_CMP_F64);
-        }
+        if (KIND == 0) { R32(GROUP8(OP_ADD_F64);) }
+        if (KIND == 1) { R32(GROUP8(OP_MUL_F64);) }
+        if (KIND == 2) { R32(GROUP8(OP_FMA_F64);) }
+        if (KIND == 3) { R32(GROUP8(OP_MIN_F64);) }
+        if (KIND == 4) { R32(GROUP8(OP_CMP_F64);) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) k_issue_f64(double *out, unsigned long lo
 #define OP_RCP_F32(d) "v_rcp_f32 " #d ", " #d "\n"
 #define OP_MULLO(d) "v_mul_lo_u32 " #d ", " #d ", %8\n"
 #define OP_CVT(d) "v_cvt_f32_i32 " #d ", " #d "\n"
+#define OP_CNDMASK64(d) "v_cndmask_b32_e64 " #d ", " #d ", %8, vcc\n"
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_issue_b32(unsigned *out, unsigned long long *clk, unsigned b, unsigned c)
@@ -70,16 +71,14 @@ __global__ void __launch_bounds__(256) k_issue_b32(unsigned *out, unsigned long 
     asm volatile("v_cmp_lt_u32 vcc, %0, %1" ::"v"(a0), "v"(b) : "vcc");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < kTrips; ++t) {
-#pragma unroll
-        for (int r = 0; r < kRep; ++r) {
-            if (KIND == 0) GROUP8I(OP_ADD_U32);
-            if (KIND == 1) GROUP8I(OP_CNDMASK);
-            if (KIND == 2) GROUP8I(OP_DPP);
-            if (KIND == 3) GROUP8I(OP_FMA_F32);
-            if (KIND == 4) GROUP8I(OP_RCP_F32);
-            if (KIND == 5) GROUP8I(OP_MULLO);
-            if (KIND == 6) GROUP8I(OP_CVT);
-        }
+        if (KIND == 0) { R32(GROUP8I(OP_ADD_U32);) }
+        if (KIND == 1) { R32(GROUP8I(OP_CNDMASK);) }
+        if (KIND == 2) { R32(GROUP8I(OP_DPP);) }
+        if (KIND == 3) { R32(GROUP8I(OP_FMA_F32);) }
+        if (KIND == 4) { R32(GROUP8I(OP_RCP_F32);) }
+        if (KIND == 5) { R32(GROUP8I(OP_MULLO);) }
+        if (KIND == 6) { R32(GROUP8I(OP_CVT);) }
+        if (KIND == 7) { R32(GROUP8I(OP_CNDMASK64);) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -124,6 +123,22 @@ __global__ void __launch_bounds__(1024) k_lds_add(unsigned *out, unsigned long l
     for (int i = threadIdx.x; i < kWinDwords; i += blockDim.x) sum += win[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+// ---- part 3: dependent chains (what one lane pays per step of a serial recurrence, k_pose_compose) ----------------
+template <int KIND>
+__global__ void __launch_bounds__(64) k_dep(double *out, unsigned long long *clk, double b, double c, int trips)
+{
+    if (KIND == 2) __builtin_amdgcn_s_setprio(3);
+    double a = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < trips; ++t) {
+        if (KIND == 0 || KIND == 2) { R32(asm volatile("v_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1" : "+v"(a) : "v"(b));) }
+        if (KIND == 1) { R32(asm volatile("v_add_f64 %0, %0, %1\nv_add_f64 %0, %0, -%2" : "+v"(a) : "v"(b), "v"(c));) }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x] = a;
+    if (threadIdx.x == 0) clk[0] = t1 - t0;
 }
 
 template <typename F>
@@ -176,7 +191,11 @@ int main()
         RUN_F64(3, "v_min_f64");
         RUN_F64(4, "v_cmp_lt_f64");
         RUN_B32(0, "v_add_u32");
-        RUN_B32(1, "v_cndmask_b32");
+        // (the 4-byte VOP2 encoding of the select, back to back, issues four to ten times slower than its 8-byte VOP3 encoding
+        // reading the same vcc.  It does not show in the real kernels: libslamhip built with every v_cndmask_b32_e32
+        // re-encoded as _e64 - 9 504 of them in icp_kernels.hip - ran k_icp in 0.104 ms, the same as before: round 4.)
+        RUN_B32(1, "v_cndmask_b32 (VOP2)");
+        RUN_B32(7, "v_cndmask_b32_e64");
         RUN_B32(2, "v_mov_b32_dpp");
         RUN_B32(3, "v_fma_f32");
         RUN_B32(4, "v_rcp_f32");
@@ -203,6 +222,21 @@ int main()
             const double cycles = (double)hclk[0];                   // in-kernel, workgroup 0 (zeroing and the final sum excluded)
             printf("%-14s waves/CU %2d: %.3f ms, %.2f GHz, %.2f adds per cycle per CU, %.3e adds/s on %d CUs\n", names[pat], waves, ms, ghz,
                    adds / cycles, adds / cycles * ghz * 1e9 * cus, cus);
+        }
+    }
+    printf("# part 3: one wave alone, a chain of dependent float64 adds; cycles per instruction\n");
+    {
+        const int trips = 1000;
+        const char *names[3] = {"v_add_f64, dependent", "(v + a) - b, dependent pair", "v_add_f64, dependent, s_setprio 3"};
+        for (int kind = 0; kind < 3; ++kind) {
+            for (int rep = 0; rep < 2; ++rep) {
+                if (kind == 0) hipLaunchKernelGGL(k_dep<0>, dim3(1), dim3(64), 0, 0, (double *)out, clk, 1.0000001, 0.5, trips);
+                if (kind == 1) hipLaunchKernelGGL(k_dep<1>, dim3(1), dim3(64), 0, 0, (double *)out, clk, 1.0000001, 0.5, trips);
+                if (kind == 2) hipLaunchKernelGGL(k_dep<2>, dim3(1), dim3(64), 0, 0, (double *)out, clk, 1.0000001, 0.5, trips);
+                CHECK(hipDeviceSynchronize());
+            }
+            CHECK(hipMemcpy(hclk, clk, 8, hipMemcpyDeviceToHost));
+            printf("%-36s %.2f cycles per add\n", names[kind], (double)hclk[0] / (trips * 64.0));
         }
     }
     return 0;
