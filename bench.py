@@ -65,7 +65,7 @@ F64_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
 SIMD_CYCLES_PER_S = 1024 * 2.4e9
 # Issue cost of a wave instruction on one SIMD, cycles, measured with four waves per SIMD (tools/ubench_issue.hip,
 # profiles/r04_ubench_issue.txt): every float64 instruction incl. compares and min / max 4.2; DPP moves, conversions, 32-bit
-# integer multiplies 4.2-4.3; v_rcp_f32 and the like 8.3; float64 rcp / rsq / sqrt twice that; plain 32-bit ones 2.35
+# integer multiplies and selects (v_cndmask_b32) 4.2-4.3; v_rcp_f32 and the like 8.3; float64 rcp / rsq / sqrt twice that; plain 32-bit ones 2.35
 ISSUE_COST = {"f64": 4.2, "quarter": 4.25, "trans_f32": 8.3, "trans_f64": 16.6, "simple": 2.35}
 # ds_add_u32 without return, 64 lanes, 16 waves per CU, every lane walking a line through a 72 KiB window of 16-bit counters
 # (the address pattern of the ray casts' walk): 5.95 adds per cycle per CU = 3.68e12 /s on 256 CUs; random dwords 5.56,
@@ -267,7 +267,7 @@ def issue_cycles(pmc, insts=None):
     st = (pmc.get("issue_mix") or {}).get("static_classes")
     if st and st.get("f64_arith"):
         n["f64_cmp_minmax_est"] = n["f64_arith"] * st["f64_cmp_minmax"] / float(st["f64_arith"])
-        n["dpp_lane_est"] = n["f64_arith"] * st["dpp_lane"] / float(st["f64_arith"])
+        n["dpp_lane_est"] = n["f64_arith"] * (st["dpp_lane"] + st.get("cndmask", 0)) / float(st["f64_arith"])      # (selects issue at the same quarter rate)
     else:
         n["f64_cmp_minmax_est"] = n["dpp_lane_est"] = 0.0
     rest = max(insts - sum(n.values()), 0.0)
@@ -276,7 +276,7 @@ def issue_cycles(pmc, insts=None):
     n["simple"] = rest
     return cyc, {"instructions": n, "cycles_per_instruction": cyc / insts, "cost_cycles": ISSUE_COST,
                  "counters": hw.get("source"), "costs": "profiles/r04_ubench_issue.txt (tools/ubench_issue.hip)",
-                 "estimated": "float64 compares / min / max and DPP / lane exchanges have no hardware counter: static share of the kernel's ISA relative to its float64 arithmetic"}
+                 "estimated": "float64 compares / min / max, DPP / lane exchanges and selects have no hardware counter: static share of the kernel's ISA relative to its float64 arithmetic"}
 
 
 # --------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ def test_issue_cycles_prices_counted_instruction_classes():
     import bench
     pmc = {"valu_insts_per_launch": 1000.0,
            "issue_mix_hw": {"f64_arith": 300.0, "f64_trans": 10.0, "cvt": 20.0, "trans_f32": 5.0, "int32": 100.0, "source": "x"},
-           "issue_mix": {"static_classes": {"f64_arith": 3000, "f64_cmp_minmax": 1500, "dpp_lane": 600}}}
+           "issue_mix": {"static_classes": {"f64_arith": 3000, "f64_cmp_minmax": 1500, "dpp_lane": 400, "cndmask": 200}}}
     cyc, detail = bench.issue_cycles(pmc)
     c = bench.ISSUE_COST
     n = detail["instructions"]

@@ -28,7 +28,7 @@ def main():
         ops = re.findall(r"^\s+(v_\w+)([^\n]*)", body, re.M)
         if not ops:
             sys.exit("isa_mix.py: kernel %s not found in the ISA of icp_kernels.hip (template arguments changed?)" % sym)
-        c = {"f64_arith": 0, "f64_cmp_minmax": 0, "f64_other": 0, "dpp_lane": 0, "cvt_mulint": 0, "trans_f32": 0, "simple": 0}
+        c = {"f64_arith": 0, "f64_cmp_minmax": 0, "f64_other": 0, "dpp_lane": 0, "cvt_mulint": 0, "trans_f32": 0, "cndmask": 0, "simple": 0}
         for op, rest in ops:
             if "dpp" in op or "quad_perm" in rest or "row_" in rest or re.search(r"permlane|readlane|readfirstlane|writelane", op):
                 c["dpp_lane"] += 1
@@ -42,6 +42,8 @@ def main():
                 c["cvt_mulint"] += 1
             elif re.search(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_f32", op):
                 c["trans_f32"] += 1
+            elif op.startswith("v_cndmask"):
+                c["cndmask"] += 1
             else:
                 c["simple"] += 1
         out[name] = {"valu": len(ops), "f64": c["f64_arith"] + c["f64_cmp_minmax"] + c["f64_other"], "classes": c}
@@ -51,7 +53,7 @@ def main():
            "kernel": "k_icp<double, 2, 4> (both passes, every search path)", "qpt3": out["qpt3"],
            "note": "static count over the kernel's ISA (hipcc -S): f64_arith = v_add / mul / fma / fmac_f64 (what the hardware's SQ_INSTS_VALU_ADD / MUL / FMA_F64 counters count), "
                    "f64_cmp_minmax = v_cmp*_f64, v_min / max_f64 (float64 issue rate, no counter of their own), dpp_lane = DPP moves, permlane, readlane (quarter rate), "
-                   "cvt_mulint = conversions and 32-bit integer multiplies (quarter rate), trans_f32 = v_rcp / sqrt / ..._f32; issue costs: profiles/r04_ubench_issue.txt"}
+                   "cvt_mulint = conversions and 32-bit integer multiplies (quarter rate), cndmask = selects (4.3 cycles in their VOP3 encoding), trans_f32 = v_rcp / sqrt / ..._f32; issue costs: profiles/r04_ubench_issue.txt"}
     json.dump(res, open(sys.argv[1], "w"), indent=1)
     print(res)
 
