@@ -591,7 +591,7 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
         elapsed = float(t.item())
     res = {"wl": wl, "elapsed": elapsed, "elapsed_local": elapsed_local, "enqueue": enqueue, "fam": fam, "closing_ms": closing_ms,
            "n_ranks": world, "dev_results": wl.collect(), "single": None, "sustained": None, "fam_note": None,
-           "timing_mask": [dominant] if lean else ("all" if not args.no_timing else []), "instrumented": None}
+           "timing_mask": [dominant] if lean else ("all" if not args.no_timing else []), "instrumented": None, "single_pipelined": None}
     if args.no_timing:
         return res
     if lean:
@@ -635,6 +635,19 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
                          "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam1.items() if v[1] > 0}}
         w1.close()
         del w1
+        if args.config != "particles" and not args.pipeline:
+            # one trajectory at a time with the context's three-stream pipeline (scan matching | pose composition | map stage
+            # of consecutive replays overlap): what ONE stream of replays reaches without a second context
+            ap = argparse.Namespace(**vars(args))
+            ap.pipeline = 1
+            wp = Workload(slam, torch, ap, env.rank, env.local, 1, slots)
+            for _ in range(args.warmup):
+                step(wp)
+            fence(wp, coll=False)
+            ep, _, _, _ = timed(wp, args.steps, coll=False)
+            res["single_pipelined"] = {"lanes": 1, "pipeline": 1, "ms_per_step": ep / args.steps * 1e3, "value": wp.units_per_step * args.steps / ep}
+            wp.close()
+            del wp
     elif len(wl.contexts()) == 1:
         res["single"] = {"lanes": 1, "ms_per_step": elapsed_local / args.steps * 1e3, "value": wl.units_per_step * args.steps / elapsed_local,
                          "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam.items() if v[1] > 0}, "note": "the main measurement is single-stream"}
@@ -761,7 +774,7 @@ def roofline_of(args, res):
 
 def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, workload, units_per_step, lanes, roofline, use_dist,
                   single=None, sustained=None, parity=None, cpu_baseline=None, other_configs=None, single_gpu_same_workload=None,
-                  rccl_world_size=None, timing_mask=None, instrumented=None):
+                  rccl_world_size=None, timing_mask=None, instrumented=None, single_pipelined=None):
     """The ONE JSON line (a dict) from measured numbers.  Pure: tests/test_bench_cpu.py checks the schema of the N = 1
     and N > 1 lines with made-up measurements."""
     out = {
@@ -784,6 +797,8 @@ def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, wor
         out["instrumented"] = instrumented
     if single:
         out["single_stream"] = single
+    if single_pipelined:
+        out["single_stream_pipelined"] = single_pipelined
     if sustained:
         out["sustained"] = sustained
     if parity is not None:
@@ -810,6 +825,8 @@ def other_config_summary(args, res, roofline, parity):
          "parity": parity}
     if res["single"]:
         r["single_stream"] = res["single"]
+    if res.get("single_pipelined"):
+        r["single_stream_pipelined"] = res["single_pipelined"]
     if res["sustained"]:
         r["sustained"] = {k: res["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")}
     r["timing_mask"] = res.get("timing_mask")
@@ -932,7 +949,8 @@ def main():
         out = assemble_line(args, n_ranks, value, res["elapsed"] / args.steps * 1e3, res["enqueue"] / args.steps * 1e3, res["closing_ms"],
                             wl_name, units, lanes, roofline, use_dist, single=single, sustained=sustained, parity=parity, cpu_baseline=cpu,
                             other_configs=others, single_gpu_same_workload=same_workload,
-                            rccl_world_size=n_ranks if use_dist else None, timing_mask=res.get("timing_mask"), instrumented=res.get("instrumented"))
+                            rccl_world_size=n_ranks if use_dist else None, timing_mask=res.get("timing_mask"), instrumented=res.get("instrumented"),
+                            single_pipelined=res.get("single_pipelined"))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
