@@ -31,6 +31,19 @@
 
 namespace slam {
 
+#ifdef SLAM_STAMPS_ICP
+__device__ unsigned long long g_polar_lanes[4];
+hipError_t debug_polar_lanes(unsigned long long out[4], bool clear)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_polar_lanes), sizeof(unsigned long long) * 4);
+    if (e == hipSuccess && clear) {
+        const unsigned long long zero[4] = {0ull, 0ull, 0ull, 0ull};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_polar_lanes), zero, sizeof zero);
+    }
+    return e;
+}
+#endif
+
 __device__ __forceinline__ double ld(const double *p, long i) { return p[i]; }
 __device__ __forceinline__ double ld(const float *p, long i) { return (double)p[i]; }
 __device__ __forceinline__ double ld(const __half *p, long i) { return (double)__half2float(p[i]); }
@@ -500,7 +513,9 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         // Every lane runs every trip of its wave - no lane mask inside the loop, so the tie bookkeeping stays in
         // scalar registers - but a lane past its own range reads the NaN points behind the last beam (one
         // address for all such lanes: a broadcast, where reading on through real targets cost LDS bandwidth).
+        int trips = 0;                                               // (used by the diagnostic build only)
         if (UNROLL == 4) for (int k = a0; __any(k <= a1); k += 4) {
+            ++trips;
             const int kc = k <= a1 ? k : n_tar;
             const double2 *t = tarP + kc;
             const double2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
@@ -512,6 +527,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
             b.take(d3, kc + 3);
         }
         else for (int k = a0; __any(k <= a1); k += 2) {
+            ++trips;
             const int kc = k <= a1 ? k : n_tar;
             const double2 *t = tarP + kc;
             const double2 t0 = t[0], t1 = t[1];
@@ -520,6 +536,8 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
             b.take(d0, kc);
             b.take(d1, kc + 1);
         }
+        ISTAMP_SCAN(wmax != kPolarMax, a1 >= a0 ? a1 - a0 + 1 : 0, trips, UNROLL);
+        (void)trips;
     };
     bool fits = window(seed, lo, hi);
     // (PROBE: for the listed queries of a first iteration, nn_listed.  Until the end of round 3 the lanes of the

@@ -562,6 +562,17 @@ int slam_debug_read(slam_ctx *c, void *out256, int clear)
     return SLAM_OK;
 }
 #endif
+#ifdef SLAM_STAMPS_ICP
+/* diagnostic build: lane efficiency counters of the beam-window search (slam_stamps.h, ISTAMP_SCAN): own candidates and
+   candidate slots of the first iteration, of the later ones */
+int slam_debug_lanes(slam_ctx *c, unsigned long long *out4, int clear)
+{
+    TRY(use(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(slam::debug_polar_lanes(out4, clear != 0));
+    return SLAM_OK;
+}
+#endif
 #ifdef SLAM_STAMPS
 /* diagnostic build: the per-workgroup records (8 dwords each, slam_stamps.h) of the launches since the last clear */
 int slam_debug_records(slam_ctx *c, void *out, int max_records)

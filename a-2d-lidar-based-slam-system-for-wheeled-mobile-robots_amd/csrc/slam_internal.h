@@ -112,6 +112,10 @@ hipError_t launch_scan_to_points(const float *ranges, const double *cos_t, const
 hipError_t launch_pose_compose(const double *T, const double *pose0, int L, int n, double *poses, hipStream_t s,
                                const double *prior = nullptr, double *heading_cs = nullptr);
 
+#ifdef SLAM_STAMPS_ICP
+hipError_t debug_polar_lanes(unsigned long long out[4], bool clear);   // diagnostic build: lane efficiency counters of nn_polar (slam_stamps.h)
+#endif
+
 // ---- grid --------------------------------------------------------------------------
 constexpr int kMaxHitLevels = 8;
 constexpr int kVisitSlots = 256;         // power of two

@@ -59,6 +59,24 @@ constexpr int kStampRecords = 32768;
 // search, [2] centroid reduction, [3] products + reduction, [4] Kabsch + transform, [5] final T;
 // [6..9]: phases 1..4 of the FIRST iteration (the others hold iterations >= 1), [10] iterations, [11] pairs, [12] lifetimes,
 // [13] lifetimes on the 100 MHz clock, [14] 2^62 - earliest start, [15] latest end (100 MHz clock).
+// Lane efficiency of the beam-window search (nn_polar::scan), -DSLAM_STAMPS_ICP only: candidates inside the lanes' own
+// windows against the candidate slots the waves ran (64 lanes x trips x candidates per trip), for the first iteration
+// ([0], [1]) and the later ones ([2], [3]); slam_debug_lanes (slam_abi.hip) reads and clears them.
+#ifdef SLAM_STAMPS_ICP
+extern __device__ unsigned long long g_polar_lanes[4];
+#define ISTAMP_SCAN(first, own, trips, per_trip)                                                          \
+    do {                                                                                                 \
+        unsigned o_ = (unsigned)(own);                                                                   \
+        for (int off_ = 32; off_ > 0; off_ >>= 1) o_ += __shfl_xor(o_, off_);                            \
+        if ((threadIdx.x & 63) == 0) {                                                                   \
+            atomicAdd(&g_polar_lanes[(first) ? 0 : 2], (unsigned long long)o_);                          \
+            atomicAdd(&g_polar_lanes[(first) ? 1 : 3], (unsigned long long)(trips) * (per_trip) * 64ull); \
+        }                                                                                                \
+    } while (0)
+#else
+#define ISTAMP_SCAN(first, own, trips, per_trip)
+#endif
+
 #ifdef SLAM_STAMPS_ICP
 #define ISTAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_first = st_t0, st_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_big[4] = {0, 0, 0, 0}, st_real = __builtin_amdgcn_s_memrealtime()
 #define ISTAMP(k)                                                                                        \
