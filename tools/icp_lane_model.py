@@ -71,6 +71,18 @@ def main():
                 ts = trips[order]
                 for a in range(0, n, 64):
                     tot["wave_sorted"] += int(ts[a:a + 64].max())
+                # partition only: queries with more than `thr` trips go to the end of the position range
+                for thr in (1, 2):
+                    wide = trips > thr
+                    order_p = np.concatenate([np.flatnonzero(~wide), np.flatnonzero(wide)])
+                    tp = trips[order_p]
+                    tot_p = 0
+                    lane_p = np.arange(n) % threads; slot_p = np.arange(n) // threads; wave_p = lane_p // 64
+                    for s_ in range(slot_p.max() + 1):
+                        for wv in range(threads // 64):
+                            m_ = (slot_p == s_) & (wave_p == wv)
+                            if m_.any(): tot_p += int(tp[m_].max())
+                    tot["part%d" % thr] = tot.get("part%d" % thr, 0) + tot_p
                 # counting sort into 4 bins by trips (1, 2, 3-4, 5+), dealt consecutively
                 b = np.digitize(trips, [2, 3, 5])
                 order = np.argsort(-b, kind="stable")
@@ -96,7 +108,7 @@ def main():
     print("pairs %d, later iterations %d, queries %d, without a window %d (%.2f %%)" % (pairs, tot["iters"], tot["q"], tot["big"], 100.0 * tot["big"] / tot["q"]))
     print("window width: median %d, mean %.1f, 90 %% %d, 99 %% %d, max %d; candidates per query %.2f" % (np.median(w), w.mean(), np.percentile(w, 90), np.percentile(w, 99), w.max(), tot["cand"] / tot["q"]))
     print("trips per query (own windows) %.2f" % (tot["own"] / tot["q"]))
-    for name in ("wave", "wave_sorted", "wave_bins"):
+    for name in ("wave", "wave_sorted", "wave_bins", "part1", "part2"):
         print("%-12s wave-trips per iteration %.1f, lane efficiency %.3f" % (name, tot[name] / tot["iters"], tot["own"] / (64.0 * tot[name])))
 
 
