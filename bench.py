@@ -552,11 +552,11 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(w, steps, coll=True, only=None):
+    def timed(w, steps, coll=True, only=None, events=True):
         """Time exactly `steps` steps of workload w; returns (elapsed, enqueue, {family: [ms, launches]}, t0).
-        only: the kernel families whose dispatches carry HIP events (None: all of them)."""
+        only: the kernel families whose dispatches carry HIP events (None: all of them); events=False: none at all."""
         for c in w.contexts():
-            c.timing_enable(not args.no_timing, only=only)
+            c.timing_enable(events and not args.no_timing, only=only)
         t0 = time.perf_counter()
         for _ in range(steps):
             step(w)
@@ -600,6 +600,9 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
         e_all, _, _, _ = timed(wl, args.steps, coll=False)
         res["instrumented"] = {"value": wl.units_per_step * args.steps / e_all, "ms_per_step": e_all / args.steps * 1e3, "timing_mask": "all",
                                "note": "the K steps repeated with HIP events on the dispatches of every kernel family; per-GPU figure, no collective inside"}
+        # ... and with none: what the library does for a caller that does not ask for kernel times
+        e_none, _, _, _ = timed(wl, args.steps, coll=False, events=False)
+        res["instrumented"]["no_events"] = {"value": wl.units_per_step * args.steps / e_none, "ms_per_step": e_none / args.steps * 1e3}
 
     # ---- sustained: the same workload stepped on past the contract's K steps until >= --sustain-seconds have
     #      passed, with the kernels' HIP-event times kept (the driver's K steps last a few milliseconds: all lanes
@@ -633,6 +636,10 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
         e1, _, fam1, _ = timed(w1, args.steps, coll=False)
         res["single"] = {"lanes": 1, "ms_per_step": e1 / args.steps * 1e3, "value": w1.units_per_step * args.steps / e1,
                          "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam1.items() if v[1] > 0}}
+        # (start / stop events on every dispatch keep one stream's kernels from following each other back to back: the
+        # same K steps without them)
+        e0, _, _, _ = timed(w1, args.steps, coll=False, events=False)
+        res["single"]["no_events"] = {"ms_per_step": e0 / args.steps * 1e3, "value": w1.units_per_step * args.steps / e0}
         w1.close()
         del w1
         if args.config != "particles" and not args.pipeline:
@@ -646,11 +653,16 @@ def measure(args, env, collective=True, want_single=True, want_sustained=True):
             fence(wp, coll=False)
             ep, _, _, _ = timed(wp, args.steps, coll=False)
             res["single_pipelined"] = {"lanes": 1, "pipeline": 1, "ms_per_step": ep / args.steps * 1e3, "value": wp.units_per_step * args.steps / ep}
+            ep0, _, _, _ = timed(wp, args.steps, coll=False, events=False)
+            res["single_pipelined"]["no_events"] = {"ms_per_step": ep0 / args.steps * 1e3, "value": wp.units_per_step * args.steps / ep0}
             wp.close()
             del wp
     elif len(wl.contexts()) == 1:
         res["single"] = {"lanes": 1, "ms_per_step": elapsed_local / args.steps * 1e3, "value": wl.units_per_step * args.steps / elapsed_local,
                          "kernel_ms_per_launch": {k: v[0] / v[1] for k, v in fam.items() if v[1] > 0}, "note": "the main measurement is single-stream"}
+        if want_single:
+            e0, _, _, _ = timed(wl, args.steps, coll=False, events=False)
+            res["single"]["no_events"] = {"ms_per_step": e0 / args.steps * 1e3, "value": wl.units_per_step * args.steps / e0}
     return res
 
 
