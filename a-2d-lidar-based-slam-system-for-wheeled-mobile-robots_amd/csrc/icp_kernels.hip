@@ -487,18 +487,18 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         const float y3 = y * y * y * 0.33333334f;
         const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;          // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
         const float dlo = (y >= 0.0f ? y - y3 : y) - 4e-6f;
-        // No further slack: with D = beta_k - beta_j in [delta - alpha, delta + alpha] and every gap between
-        // neighbouring beams at least 1 / inv_db, a beam k > j has k - j <= D * inv_db, hence k <= j + floor(D *
-        // inv_db) <= whi; a computed product that falls short of the true one by a rounding (1e-7 relative, the
-        // factors above give 1e-6 and more) still rounds UP to that floor unless the true value is an integer
-        // to 1e-7 - and then it is the integer itself that ceilf returns.  Likewise below j.  (Until late in
-        // round 2 there was one more beam either side "for safety": 20 % more candidates; its removal is
-        // checked against the exhaustive search by tests/test_polar_window_bound.py on the CPU and by every
-        // GPU parity test.)
+        // With D = beta_k - beta_j in [delta - alpha, delta + alpha] and every gap between neighbouring beams at
+        // least 1 / inv_db, a beam k > j has k - j <= D * inv_db, hence k <= j + floor(D * inv_db); every factor of
+        // the computed product is rounded outwards by 1e-6 and more against 1e-7 of arithmetic rounding, so the
+        // computed product is not below the true one and its floor not below the true floor.  Likewise below j
+        // with ceil.  (Until late in round 2 there was one more beam either side "for safety", until round 4 the
+        // roundings went the other way - ceil above, floor below: one beam either side of nearly every window,
+        // 4.2 instead of 2.2 candidates per query on the benchmark replay.  Checked against the exhaustive search
+        // by tests/test_polar_window_bound.py on the CPU and by every GPU parity test.)
         // (clamped to one turn either side: a window that wide is refused below, and the sums cannot wrap)
         const float fn = (float)n_tar;
-        wlo = j + (int)floorf(fmaxf(-fn, fminf(0.0f, (dlo - alpha) * geo.inv_db)));
-        whi = j + (int)ceilf(fminf(fn, fmaxf(0.0f, (dhi + alpha) * geo.inv_db)));
+        wlo = j + (int)ceilf(fmaxf(-fn, fminf(0.0f, (dlo - alpha) * geo.inv_db)));
+        whi = j + (int)floorf(fminf(fn, fmaxf(0.0f, (dhi + alpha) * geo.inv_db)));
         return small && whi - wlo < wmax;
     };
     auto scan = [&](int a0, int a1, Best &b) {
@@ -564,8 +564,11 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     const bool go = active && !big;
     // three index ranges in ascending order: wrapped from above | the window | wrapped from below
     const int m0 = max(lo, 0), m1 = min(hi, n_tar - 1);
-    const int e0 = hi > n_tar - 1 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;         // [0, e0]
-    const int s2 = lo < 0 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;                // [s2, n_tar - 1]
+    // (the scan may close on itself with its last beam up to half a beam spacing PAST its first - polar_probe admits
+    // that much: wrapped beam m lies at least n - 1 + m - 1/2 spacings above beam 0's index, so it belongs to the
+    // window when m <= hi - (n - 1) + 1, and likewise below)
+    const int e0 = hi >= n_tar - 2 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;        // [0, e0]
+    const int s2 = lo <= 1 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;               // [s2, n_tar - 1]
     Best b;
     b.start();
     const bool wraps = __any(go && (e0 >= 0 || s2 < n_tar));        // (rare: one wave-uniform test instead of two empty loops)
