@@ -166,7 +166,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int 
 // xor mask and under none of the later ones.  Afterwards lane l holds the wave total of value
 // sigma1 + 2 sigma2 (+ 4 sigma3): lanes 0..3 hold values 0..3, lanes 7, 6, 5, 4 values 4..7.
 // Fixed order: deterministic, the same in every lane that holds the same value.
-struct LaneSel { bool s1, s2, s3, s4; int idx8, idx4, idx16; };
+struct LaneSel { bool s1, s2, s3; int idx8, idx4; };
 __device__ __forceinline__ LaneSel lane_sel(int lane)
 {
     LaneSel s;
@@ -175,8 +175,6 @@ __device__ __forceinline__ LaneSel lane_sel(int lane)
     s.s3 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0;
     s.idx4 = (s.s1 ? 1 : 0) + (s.s2 ? 2 : 0);
     s.idx8 = s.idx4 + (s.s3 ? 4 : 0);
-    s.s4 = ((lane >> 3) & 1) != 0;                     // flips under the row mirror (xor 15), the last exchange
-    s.idx16 = s.idx8 + (s.s4 ? 8 : 0);
     return s;
 }
 template <int CTRL>
@@ -213,25 +211,14 @@ __device__ __forceinline__ double wave_reduce4(const double (&v)[4], const LaneS
     u += dpp_xchg<0x140>(u);
     return rows_sum_f64(u);
 }
-// Nine values: one more halving step at the row mirror (selection bit b3).  Afterwards lane l holds the wave total
-// of value idx16(l): values 0..7 where wave_reduce8 leaves them, value 8 in lane 15; idx16 9..15 hold zeros.
-__device__ __forceinline__ double wave_reduce9(const double (&v)[9], const LaneSel &s)
-{
-    const double r0 = tstep<0xB1>(v[0], v[1], s.s1), r1 = tstep<0xB1>(v[2], v[3], s.s1);
-    const double r2 = tstep<0xB1>(v[4], v[5], s.s1), r3 = tstep<0xB1>(v[6], v[7], s.s1);
-    const double r4 = tstep<0xB1>(v[8], 0.0, s.s1);
-    const double t0 = tstep<0x4E>(r0, r1, s.s2), t1 = tstep<0x4E>(r2, r3, s.s2), t2 = tstep<0x4E>(r4, 0.0, s.s2);
-    const double x0 = tstep<0x141>(t0, t1, s.s3), x1 = tstep<0x141>(t2, 0.0, s.s3);
-    return rows_sum_f64(tstep<0x140>(x0, x1, s.s4));
-}
 // Workgroup total of the value this lane holds after wave_reduce8 / 4: lanes 0..7 of every wave
-// (0..15 with nine values) leave theirs in scratch[wave][value], and after the barrier every lane adds its
+// leave theirs in scratch[wave][value], and after the barrier every lane adds its
 // value's column in wave order.  `scratch` ([nwaves][NV]) alternates between two buffers on consecutive calls.
 template <int NV = 8>
 __device__ __forceinline__ double block_total(double mine, int idx, double *scratch, int nwaves, int wave, int lane)
 {
     if (nwaves == 1) return mine;
-    if (lane < (NV > 8 ? 16 : 8) && idx < NV) scratch[wave * NV + idx] = mine;
+    if (lane < 8 && idx < NV) scratch[wave * NV + idx] = mine;
     __syncthreads();
     return lds_column(scratch + min(idx, NV - 1), NV, nwaves);
 }
@@ -823,10 +810,10 @@ __device__ __forceinline__ void stage_target(const Cloud<T> &tar, int n_tar, dou
 // ---------------------------------------------------------------------------------
 constexpr int kIcpExtraLds = 32;               // flag words: source set collapsed, count of listed queries, re-do
 __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n_tar + kPolarTail) * sizeof(double2); }
-// cross-wave stage of the reductions ([2][nwaves][9] doubles: the nine values of the one-pass iteration; 144 B a wave, so
+// cross-wave stage of the reductions ([2][nwaves][8] doubles: seven values in the one-pass iteration; 128 B a wave, so
 // what follows stays 16-byte aligned) and of the collapsed-set test ([2][nwaves][4]: matched point of the wave's first
 // query, "this wave saw another"), two alternating buffers each
-constexpr int kRedStride = 9;
+constexpr int kRedStride = 8;
 __host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double); }
 
 // EXACT: the second pass over a pair in which the first saw a best undercut its predecessor by less than a class of
@@ -1067,27 +1054,30 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             // and the exact centroids and centred products follow algebraically,
             //   c_A = p + S_a / N,  c_B = p + S_b / N,  W = sum (b - p)(a - p)^T - S_b S_a^T / N,
             // with S_a = sum (a - p) at rounding level - the correction is of the order of the last place of W.
-            double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // The rotation needs W only through A = W00 + W11 and B = W10 - W01 (kabsch_from_sums): the two are summed
+            // directly - seven values instead of nine, one exchange level less in the wave reduction.
+            double u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < QPT; ++q) {
                 if (ok[q]) {
                     const double dax = sx[q] - pcx, day = sy[q] - pcy, dbx = mx[q] - pcx, dby = my[q] - pcy;
                     u[0] += dax; u[1] += day; u[2] += dbx; u[3] += dby; u[4] += dq[q];
-                    u[5] += dbx * dax; u[6] += dbx * day; u[7] += dby * dax; u[8] += dby * day;
+                    u[5] += dbx * dax + dby * day; u[6] += dby * dax - dbx * day;
                 }
             }
             ISTAMP(1);
-            const double tot = block_total<9>(wave_reduce9(u, ls), ls.idx16, red + par * nwaves * kRedStride, nwaves, wave, lane);
+            const double tot = block_total<8>(wave_reduce8(u, ls), ls.idx8, red + par * nwaves * kRedStride, nwaves, wave, lane);
             const double qv = tot / dn;                              // icp.py:154-155, :75
             const double qax = readlane_f64(qv, 0), qay = readlane_f64(qv, 1);
             cax = pcx + qax; cay = pcy + qay;
             cbx = pcx + readlane_f64(qv, 2); cby = pcy + readlane_f64(qv, 3);
-            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7, values 5..7 in lanes 6, 5, 4, value 8 in lane 15
+            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7, values 5, 6 in lanes 6, 5
             const double sbx = readlane_f64(tot, 2), sby = readlane_f64(tot, 3);
-            w[0] = readlane_f64(tot, 6) - sbx * qax; w[1] = readlane_f64(tot, 5) - sbx * qay;
-            w[2] = readlane_f64(tot, 4) - sby * qax; w[3] = readlane_f64(tot, 15) - sby * qay;
+            w[0] = readlane_f64(tot, 6) - (sbx * qax + sby * qay);   // A
+            w[2] = readlane_f64(tot, 5) - (sby * qax - sbx * qay);   // B
+            w[1] = w[3] = 0.0;
             ISTAMP(3);
-            if (targets_collapsed() || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+            if (targets_collapsed() || src_collapsed) w[0] = w[2] = 0.0;
         }
         Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
 #pragma unroll

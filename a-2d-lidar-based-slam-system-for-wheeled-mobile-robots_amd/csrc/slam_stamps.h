@@ -62,7 +62,9 @@ constexpr int kStampRecords = 32768;
 // Lane efficiency of the beam-window search (nn_polar::scan), -DSLAM_STAMPS_ICP only: candidates inside the lanes' own
 // windows against the candidate slots the waves ran (64 lanes x trips x candidates per trip), for the first iteration
 // ([0], [1]) and the later ones ([2], [3]); slam_debug_lanes (slam_abi.hip) reads and clears them.
-#ifdef SLAM_STAMPS_ICP
+// (-DSLAM_STAMPS_ICP=3: the phase timers alone - the lane counters' atomics, four addresses for every wave of the launch,
+// stretch a pair's lifetime tenfold and with it every phase)
+#if defined(SLAM_STAMPS_ICP) && SLAM_STAMPS_ICP != 3
 extern __device__ unsigned long long g_polar_lanes[4];
 #define ISTAMP_SCAN(first, own, trips, per_trip)                                                          \
     do {                                                                                                 \
