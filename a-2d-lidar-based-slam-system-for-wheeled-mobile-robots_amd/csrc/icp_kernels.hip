@@ -814,7 +814,7 @@ __host__ __device__ inline size_t icp_polar_bytes(int n_tar) { return (size_t)(n
 // what follows stays 16-byte aligned) and of the collapsed-set test ([2][nwaves][4]: matched point of the wave's first
 // query, "this wave saw another"), two alternating buffers each
 constexpr int kRedStride = 8;
-__host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double); }
+__host__ __device__ inline size_t icp_red_bytes(int nwaves) { return (size_t)2 * nwaves * (kRedStride + 4) * sizeof(double) + 8 * sizeof(double); }   // + what a pair's first wave hands the others (kLead)
 
 // EXACT: the second pass over a pair in which the first saw a best undercut its predecessor by less than a class of
 // equal distances (see "Best"): the same solve with the reference's own nearest-neighbour loop (nn_exact).
@@ -835,7 +835,8 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     double *red = reinterpret_cast<double *>(smem + nn_lds_bytes(a.n_tar) + p_bytes);             // [2][nwaves][kRedStride]
     double *cref = red + 2 * nwaves * kRedStride;                                                // [2][nwaves][4]
-    unsigned *geo = reinterpret_cast<unsigned *>(cref + 2 * nwaves * 4);                          // [8] flags: [3] source set collapsed, [4] queries listed for nn_listed, [5] re-do (the others unused)
+    double *lead = cref + 2 * nwaves * 4;                                                        // [8]: rotation, translation, centroid, mean error from the pair's first wave (kLead)
+    unsigned *geo = reinterpret_cast<unsigned *>(lead + 8);                          // [8] flags: [3] source set collapsed, [4] queries listed for nn_listed, [5] re-do (the others unused)
     double2 *qlist = reinterpret_cast<double2 *>(geo + 8);                                      // [a.team_cap] nn_listed
     int *qseed = reinterpret_cast<int *>(qlist + a.team_cap);                                    // [a.team_cap]
     char *guard = reinterpret_cast<char *>(qseed + a.team_cap);
@@ -924,6 +925,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     // for nn_listed), the loop behind it takes the one-pass form; returns true when the solve has converged (icp.py:76-77)
     auto iterate = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool kLead = QPT >= 3 && !EXACT;                   // launch shapes for a full chip: see `finish` below
         double mx[QPT], my[QPT], dq[QPT];
         // first iteration over a scan: queries without a usable beam window are listed (nn_listed)
         const bool team_it = FIRST && !EXACT && a.team_cap > 0 && pg.inv_db > 0.0f;
@@ -1014,6 +1016,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             return !__any(mine[2] != 0.0 || !(mine[0] == cr[0] && mine[1] == cr[1]));
         };
         double cax, cay, cbx, cby, w[4];
+        Rigid2 r;
         if (FIRST || !kOnePass) {
             // Two passes, as the reference (centroids, then centred products, icp.py:154-160).
             double v[5] = {0, 0, 0, 0, 0};
@@ -1066,20 +1069,49 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
                 }
             }
             ISTAMP(1);
-            const double tot = block_total<8>(wave_reduce8(u, ls), ls.idx8, red + par * nwaves * kRedStride, nwaves, wave, lane);
-            const double qv = tot / dn;                              // icp.py:154-155, :75
-            const double qax = readlane_f64(qv, 0), qay = readlane_f64(qv, 1);
-            cax = pcx + qax; cay = pcy + qay;
-            cbx = pcx + readlane_f64(qv, 2); cby = pcy + readlane_f64(qv, 3);
-            mean_error = readlane_f64(qv, 7);                        // value 4 lives in lane 7, values 5, 6 in lanes 6, 5
-            const double sbx = readlane_f64(tot, 2), sby = readlane_f64(tot, 3);
-            w[0] = readlane_f64(tot, 6) - (sbx * qax + sby * qay);   // A
-            w[2] = readlane_f64(tot, 5) - (sby * qax - sbx * qay);   // B
-            w[1] = w[3] = 0.0;
-            ISTAMP(3);
-            if (targets_collapsed() || src_collapsed) w[0] = w[2] = 0.0;
+            // what follows the sums: the quotients, the rotation, the translation - a hundred instructions on wave-uniform
+            // values.  In the launch shapes for a full chip (kLead: three queries per lane and more) the pair's first wave
+            // does them alone and leaves the result in LDS behind a second barrier - the waves that wait leave their issue
+            // slots to other pairs (10 000 pairs: 0.388 -> ? ms); a launch that cannot fill the chip is bound by a pair's
+            // own latency, and there every wave computes them for itself behind the ONE barrier.
+            auto finish = [&](const double tot) __attribute__((always_inline)) {
+                const double qv = tot / dn;                          // icp.py:154-155, :75
+                const double qax = readlane_f64(qv, 0), qay = readlane_f64(qv, 1);
+                cax = pcx + qax; cay = pcy + qay;
+                cbx = pcx + readlane_f64(qv, 2); cby = pcy + readlane_f64(qv, 3);
+                mean_error = readlane_f64(qv, 7);                    // value 4 lives in lane 7, values 5, 6 in lanes 6, 5
+                const double sbx = readlane_f64(tot, 2), sby = readlane_f64(tot, 3);
+                w[0] = readlane_f64(tot, 6) - (sbx * qax + sby * qay);   // A
+                w[2] = readlane_f64(tot, 5) - (sby * qax - sbx * qay);   // B
+                w[1] = w[3] = 0.0;
+                ISTAMP(3);
+                if (targets_collapsed() || src_collapsed) w[0] = w[2] = 0.0;
+                r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
+            };
+            if (kLead && nwaves > 1) {
+                double *sc = red + par * nwaves * kRedStride;
+                const double mine = wave_reduce8(u, ls);
+                if (lane < 8) sc[wave * 8 + ls.idx8] = mine;
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+                    finish(lds_column(sc + ls.idx8, 8, nwaves));
+                    if (lane == 0) {
+                        double2 *l2 = reinterpret_cast<double2 *>(lead);
+                        l2[0] = make_double2(r.c, r.s); l2[1] = make_double2(r.tx, r.ty);
+                        l2[2] = make_double2(cbx, cby); l2[3] = make_double2(mean_error, 0.0);
+                    }
+                }
+                __syncthreads();
+                const double2 *l2 = reinterpret_cast<const double2 *>(lead);
+                const double2 v0 = l2[0], v1 = l2[1], v2 = l2[2], v3 = l2[3];
+                r.c = v0.x; r.s = v0.y; r.tx = v1.x; r.ty = v1.y;
+                cbx = readlane_f64(v2.x, 0); cby = readlane_f64(v2.y, 0);
+                mean_error = readlane_f64(v3.x, 0);
+            } else {
+                finish(block_total<8>(wave_reduce8(u, ls), ls.idx8, red + par * nwaves * kRedStride, nwaves, wave, lane));
+            }
         }
-        Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
+        if (FIRST || !kOnePass) r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);    // :69
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {                              // src = T.src (:71)
             double nx = r.c * sx[q] + (-r.s) * sy[q] + r.tx;
