@@ -422,9 +422,9 @@ __device__ __forceinline__ void nn_search(const double2 *__restrict__ tarL, cons
 // that must lie on a ray that passes within sqrt(U) of s: |angle(s) - beta_k| <= asin(sqrt(U) /
 // rs).  With beams ordered by angle and spaced at least dbeta apart that is a window of beam
 // INDICES around the seed's beam j: angle(s) = beta_j + delta with tan(delta) = cross(t_j, s) /
-// dot(t_j, s), so k - j lies in [(delta - alpha) / dbeta, (delta + alpha) / dbeta] - typically 2-6
+// dot(t_j, s), so k - j lies in [(delta - alpha) / dbeta, (delta + alpha) / dbeta] - typically 1-3
 // beams instead of the 30-40 points + 15 boxes the box search touches (measured on the benchmark
-// scans: median 6 candidates per query, 90 % <= 9).  The window is evaluated in float32 with
+// scans in the iterations after the first: median 2 candidates per query, mean 2.4, 90 % <= 4).  The window is evaluated in float32 with
 // every rounding pushed outwards (plus the angular slack
 // of points rounded to their storage type), the candidates inside it are compared exactly as
 // everywhere else (float64 dist2, ascending index, strict '<'), and a ray outside it holds only
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             // what follows the sums: the quotients, the rotation, the translation - a hundred instructions on wave-uniform
             // values.  In the launch shapes for a full chip (kLead: three queries per lane and more) the pair's first wave
             // does them alone and leaves the result in LDS behind a second barrier - the waves that wait leave their issue
-            // slots to other pairs (10 000 pairs: 0.388 -> ? ms); a launch that cannot fill the chip is bound by a pair's
+            // slots to other pairs (10 000 pairs: 0.388 -> 0.381 ms); a launch that cannot fill the chip is bound by a pair's
             // own latency, and there every wave computes them for itself behind the ONE barrier.
             auto finish = [&](const double tot) __attribute__((always_inline)) {
                 const double qv = tot / dn;                          // icp.py:154-155, :75
