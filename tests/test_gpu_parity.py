@@ -246,6 +246,31 @@ def test_replay_largest_scans_vs_oracle(slam, syn, beams):
     ctx.close()
 
 
+@pytest.mark.parametrize("gap", [5.3e-6, 0.0, -0.45, 0.6, 1.0])
+@pytest.mark.parametrize("n", [360, 90])
+def test_replay_scans_that_close_on_themselves(slam, syn, n, gap):
+    """Full-circle scans whose last beam lies `gap` beam spacings before the first again (the benchmark's linspace(-3.14159,
+    3.14159) leaves 5.3e-6 rad; a scan may even overlap itself by up to half a spacing): the beam-window search scans the
+    wrapped index ranges on both sides of the seam (csrc/icp_kernels.hip nn_polar; the rule is checked on the CPU by
+    tests/test_polar_window_bound.py::test_wrapped_ranges_of_a_scan_that_closes_on_itself).  Every other scan sees other
+    surfaces in the beams next to the seam, so that windows there are wide and cross it.  Against the oracle's exhaustive
+    search: iteration counts exact, poses and transforms to 1e-9."""
+    rng = np.random.default_rng(int(n + 100 * gap))
+    ranges = syn.make_replay(20, n, seed=31, stride=5).ranges.copy()
+    ranges[1::2, :5] *= rng.uniform(0.6, 1.5, size=ranges[1::2, :5].shape).astype(np.float32)
+    ranges[1::2, -5:] *= rng.uniform(0.6, 1.5, size=ranges[1::2, -5:].shape).astype(np.float32)
+    amin = -np.pi
+    amax = AMAX if gap == 5.3e-6 else amin + 2 * np.pi * (n - 1) / (n - 1 + gap)
+    if gap == 5.3e-6:
+        amin = AMIN
+    ctx = slam.Context(0)
+    poses, T, it = slam.replay_host(ranges, amin, amax, context=ctx)
+    ctx.close()
+    oposes, oT, oit, _ = co.replay(ranges, amin, amax, None, threads=8)
+    assert np.array_equal(it, oit)
+    assert np.max(np.abs(poses - oposes)) < FTOL and np.max(np.abs(T - oT.reshape(T.shape))) < FTOL
+
+
 @pytest.mark.parametrize("kind", ["replay", "jumps", "random", "dense", "five"])
 def test_listed_first_iteration_queries_match_the_box_search(slam, syn, kind):
     """First-iteration queries without a usable beam window are listed in LDS and searched apart from the lanes that own
