@@ -99,6 +99,15 @@ def test_device_returns_the_canonical_answer(g8):
     oT, oit, _ = co.icp_batch(np.broadcast_to(cloud, (80, 2, 3)).copy(), srcs, 30, 0.001)
     assert np.array_equal(it, oit) and np.max(np.abs(T - oT)) < 1e-9
     assert np.max(np.abs(T[:, 0, 0] - 1.0)) < 1e-12 and np.max(np.abs(T[:, 1, 0])) < 1e-12
+    # ... in every launch shape of large batches (three queries per lane: the pair's first wave finishes the iteration
+    # for the others - the collapsed-set test is then its business alone)
+    for qpt in (1, 2, 3):
+        ctx = slam.Context(0)
+        ctx.set_option("icp_qpt", qpt)
+        Tq, itq, _ = slam.icp_batch_host(np.broadcast_to(cloud, (80, 2, 3)).copy(), srcs, 30, 0.001, context=ctx)
+        ctx.close()
+        assert np.array_equal(itq, oit) and np.max(np.abs(Tq - oT)) < 1e-9, qpt
+        assert np.max(np.abs(Tq[:, 0, 0] - 1.0)) < 1e-12 and np.max(np.abs(Tq[:, 1, 0])) < 1e-12
     # collapsed source set
     src = np.tile(np.array([[0.1], [0.7]]), (1, 9))
     tar = rng.normal(0, 2, size=(2, 9))
