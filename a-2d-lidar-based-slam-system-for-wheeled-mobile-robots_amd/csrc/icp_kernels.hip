@@ -469,7 +469,7 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
         const float x2 = ((float)U * 1.000002f + 1e-30f) * __builtin_amdgcn_rcpf(rs2 * 0.999998f);   // (sqrt(U) / rs)^2, rounded up
         const bool small = x2 < 0.25f;                               // NaN: false
         const float x = __builtin_amdgcn_sqrtf(x2) * 1.000001f;
-        const float alpha = x * (1.0f + x2 * (0.16666667f + 0.1f * x2)) * 1.000002f + geo.slack;   // >= asin(x) for x < 0.5
+        const float alpha = x * (1.0f + 0.19f * x2) * 1.000002f + geo.slack;   // >= asin(x) for x < 0.5: (asin x - x) / x^3 grows from 1/6 to 0.1888 there
         const float y = (ftx * fsy - fty * fsx) * __builtin_amdgcn_rcpf(ftx * fsx + fty * fsy);       // tan(delta), |delta| <= 30 degrees
         const float y3 = y * y * y * 0.33333334f;
         const float dhi = (y >= 0.0f ? y : y - y3) + 4e-6f;          // y - y^3/3 <= atan(y) <= y for y >= 0 (mirrored below 0)
@@ -918,7 +918,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     const double dn = (double)n_src;
     const LaneSel ls = lane_sel(lane);
     ISTAMP(14);
-    double pre_error = 0.0, mean_error = 0.0, pcx = 0.0, pcy = 0.0;
+    double pre_error = 0.0, mean_error = 0.0, pcx = 0.0, pcy = 0.0, ca0x = 0.0, ca0y = 0.0;   // (ca0: centroid of the source before it moves)
     int iters = 0, par = 0;
     bool amb_any = false;
     // one iteration; FIRST: the instance for iteration 0 (two reductions as the reference; the only one that lists queries
@@ -1004,10 +1004,24 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
         bool wave_differs;
         {
             const double m0x = readlane_f64(mx[0], 0), m0y = readlane_f64(my[0], 0);
-            bool differs = false;
+            // The usual case is settled on ONE lane: some first query of the wave is matched to another beam than lane 0's
+            // (an integer compare per lane), and that beam's point differs from lane 0's.  Only when no such lane exists, or
+            // its point has the same coordinates (targets that coincide: several beams of range 0), every match is compared.
+            const int j0 = __builtin_amdgcn_readfirstlane(seed[0]);
+            const unsigned long long other = __ballot(ok[0] && seed[0] != j0);
+            bool found = false;
+            if (other != 0ull) {
+                const int l = __ffsll((long long)other) - 1;
+                const double ox = readlane_f64(mx[0], l), oy = readlane_f64(my[0], l);
+                found = !(ox == m0x && oy == m0y);
+            }
+            if (found) wave_differs = true;
+            else {
+                bool differs = false;
 #pragma unroll
-            for (int q = 0; q < QPT; ++q) differs |= ok[q] && !(mx[q] == m0x && my[q] == m0y);
-            wave_differs = __any(differs);
+                for (int q = 0; q < QPT; ++q) differs |= ok[q] && !(mx[q] == m0x && my[q] == m0y);
+                wave_differs = __any(differs);
+            }
             if (nwaves > 1 && lane == 0) { cr[4 * wave] = m0x; cr[4 * wave + 1] = m0y; cr[4 * wave + 2] = wave_differs ? 1.0 : 0.0; }
         }
         auto targets_collapsed = [&]() -> bool {                     // (call behind the barrier)
@@ -1050,6 +1064,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             }
             ISTAMP(FIRST ? 8 : 3);
             if (tar_collapsed || src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+            if (FIRST) { ca0x = cax; ca0y = cay; }
         } else {
             // From the second iteration on: ONE pass and one barrier.  The update of the iteration before moved the
             // source's centroid onto the centroid of its matches (t = c_B - R c_A), so that point p is within rounding
@@ -1132,35 +1147,70 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     // (a pair in which some lane saw a best undercut its predecessor by less than a class of equal distances is
     // re-done: the flag travels through LDS, behind the barriers of the sums below)
     if (!EXACT && amb_any) geo[5] = 1u;
-    // final T = getTransform(A_original, src_final) (icp.py:81)
-    double v[4] = {0, 0, 0, 0};
+    // final T = getTransform(A_original, src_final) (icp.py:81).  ONE reduction when an iteration has run: the originals'
+    // centroid c_A is the first iteration's source centroid (the same sums in the same order - the source had not moved yet),
+    // and the last update put the source's centroid on p = (pcx, pcy) up to rounding, so with S = sum (s - p)
+    //   c_S = p + S / N,   W = sum (s - p)(a - c_A)^T   (- S . sum (a - c_A)^T / N: rounding level times rounding level),
+    // of which the rotation needs A = W00 + W11 and B = W10 - W01 (as in the iterations).  Only the pair's first wave goes on
+    // behind the barrier: it alone stores the result.
+    Rigid2 r;
+    if (iters > 0) {
+        double u[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < QPT; ++q)
-        if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
-    // (the reductions of the iterations: transposed wave reduction, one LDS stage, ONE division sequence per stage;
-    // the same sums in the same order as block_sum, and the same quotients)
-    par ^= 1;
-    double cax, cay, cbx, cby;
-    {
-        const double tot = block_total(wave_reduce4(v, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
-        const double qv = tot / dn;
-        cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
-    }
-    double w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < QPT; ++q) {
-        if (ok[q]) {
-            double aax = ax[q] - cax, aay = ay[q] - cay, bbx = sx[q] - cbx, bby = sy[q] - cby;
-            w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
+        for (int q = 0; q < QPT; ++q) {
+            if (ok[q]) {
+                const double dsx = sx[q] - pcx, dsy = sy[q] - pcy, dax = ax[q] - ca0x, day = ay[q] - ca0y;
+                u[0] += dsx; u[1] += dsy;
+                u[2] += dsx * dax + dsy * day; u[3] += dsy * dax - dsx * day;
+            }
         }
+        par ^= 1;
+        const double mine = wave_reduce4(u, ls);
+        double tot = mine;
+        bool mine_to_finish = true;
+        if (nwaves > 1) {
+            double *sc = red + par * nwaves * kRedStride;
+            if (lane < 8 && ls.idx4 < 8) sc[wave * 8 + ls.idx4] = mine;
+            __syncthreads();
+            mine_to_finish = __builtin_amdgcn_readfirstlane(wave) == 0;
+            if (mine_to_finish) tot = lds_column(sc + ls.idx4, 8, nwaves);
+        }
+        if (mine_to_finish) {
+            const double qv = tot / dn;
+            const double csx = pcx + readlane_f64(qv, 0), csy = pcy + readlane_f64(qv, 1);
+            double wa = readlane_f64(tot, 2), wb = readlane_f64(tot, 3);
+            if (src_collapsed) wa = wb = 0.0;
+            r = kabsch_from_sums_wave(ca0x, ca0y, csx, csy, wa, 0.0, wb, 0.0, lane);
+        }
+    } else {
+        // no iteration (max_iter 0): centroids, then centred products, as the reference
+        double v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < QPT; ++q)
+            if (ok[q]) { v[0] += ax[q]; v[1] += ay[q]; v[2] += sx[q]; v[3] += sy[q]; }
+        par ^= 1;
+        double cax, cay, cbx, cby;
+        {
+            const double tot = block_total(wave_reduce4(v, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
+            const double qv = tot / dn;
+            cax = readlane_f64(qv, 0); cay = readlane_f64(qv, 1); cbx = readlane_f64(qv, 2); cby = readlane_f64(qv, 3);
+        }
+        double w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            if (ok[q]) {
+                double aax = ax[q] - cax, aay = ay[q] - cay, bbx = sx[q] - cbx, bby = sy[q] - cby;
+                w[0] += bbx * aax; w[1] += bbx * aay; w[2] += bby * aax; w[3] += bby * aay;
+            }
+        }
+        par ^= 1;
+        {
+            const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
+            w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
+        }
+        if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
+        r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);
     }
-    par ^= 1;
-    {
-        const double tot = block_total(wave_reduce4(w, ls), ls.idx4, red + par * nwaves * kRedStride, nwaves, wave, lane);
-        w[0] = readlane_f64(tot, 0); w[1] = readlane_f64(tot, 1); w[2] = readlane_f64(tot, 2); w[3] = readlane_f64(tot, 3);
-    }
-    if (src_collapsed) w[0] = w[1] = w[2] = w[3] = 0.0;
-    const Rigid2 r = kabsch_from_sums_wave(cax, cay, cbx, cby, w[0], w[1], w[2], w[3], lane);
     if (tid == 0) {
         double *To = a.T_out + 9 * (long)b;
         To[0] = r.c; To[1] = -r.s; To[2] = r.tx;
