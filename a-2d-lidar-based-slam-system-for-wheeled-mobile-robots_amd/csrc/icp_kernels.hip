@@ -1264,8 +1264,11 @@ static hipError_t launch_icp_t(const IcpArgs &a_in, hipStream_t s)
     // pair repeat the per-iteration fixed work less often: three queries per lane are fastest when
     // the chip is full (10 000 pairs: 0.510 against 0.536 ms; four overlapping 999-pair replays: 6.2
     // against 6.0 M scans/s); a launch that cannot fill the chip on its own runs shorter with two
-    // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.
-    int pref = a.qpt_pref > 0 ? a.qpt_pref : (a.B >= 2500 ? 3 : 2);
+    // (999 pairs alone: 0.121 against 0.140 ms).  a.qpt_pref: 0 = by batch size, else 1..3.  "Full" goes by the waves the
+    // batch would have at two queries per lane: from 7 500 on - 2 500 pairs of 360 beams, 834 pairs of 1 080 (999 such pairs
+    // alone: 0.338 ms with three queries per lane against 0.364 with two) - the chip holds them in more than one round.
+    const long waves_at_two = (long)a.B * ((a.n_src + 127) / 128);
+    int pref = a.qpt_pref > 0 ? a.qpt_pref : (waves_at_two >= 7500 ? 3 : 2);
     if (a.B > 64 && qpt < pref && a.n_src > 64 * pref) qpt = pref;
     if (qpt > 4) qpt = 8;                     // the shapes that exist: 1, 2, 3, 4, 8 queries per lane
     const int block = icp_block(a.n_src, qpt);

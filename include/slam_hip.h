@@ -84,8 +84,9 @@ int slam_check_status(slam_ctx *ctx);
  *   cannot fill the chip on its own - shorter launch, a little more total work), 0 = never
  *   (callers that overlap launches of several contexts), 1 = always.
  * "icp_qpt": queries per lane of batched scan matching, 1..3; 0 = by batch size (two for
- *   launches that cannot fill the chip on their own, three from 2 500 pairs; callers that
- *   overlap several smaller launches set 3).
+ *   launches that cannot fill the chip on their own, three from 2 500 pairs of 360 beams or
+ *   834 of 1 080 - 7 500 waves at two queries per lane; callers that overlap several smaller
+ *   launches set 3).
  * "replay_reset": 1 = slam_replay_dev starts its map from zero (as slam_grid_reset before it would),
  *   clearing the counters inside its scan-matching launch: one dispatch less per replay.  0
  *   (default): the map accumulates across replays until slam_grid_reset.
