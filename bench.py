@@ -727,6 +727,22 @@ def roofline_of(args, res):
             roofline["physical"] = {"achieved": traffic / (alone_ms * 1e-3) / 1e9, "unit": "GB/s", "traffic_over_algorithmic": traffic / max(alg.get(dom, 0), 1),
                                     "mixed_rw_peak_measured": MIXED_RW_PEAK_GBS,
                                     "frac_of_mixed_rw_peak": traffic / (alone_ms * 1e-3) / 1e9 / MIXED_RW_PEAK_GBS}
+    if dom != "icp" and fam.get("icp", (0.0, 0))[1]:
+        # the scan matcher of a configuration another kernel dominates, priced exactly as the replay's roofline.frac: in the
+        # particle batch its 10 000 pairs fill the chip, which the lone 999-pair launch of the replay does not
+        pk = load_pmc(args.config, "k_icp")
+        if pk.get("issue_mix_hw") and not pk.get("issue_mix"):
+            mix = load_pmc("replay", "k_icp").get("issue_mix")       # (the static classes of the same kernel: tools/isa_mix.py)
+            if mix:
+                q3 = (mix.get("qpt3") or {}).get("classes")
+                pk = dict(pk, issue_mix=dict(mix, static_classes=q3) if q3 else mix)
+        cyc_i, det_i = issue_cycles(pk)
+        icp_ms = (single["kernel_ms_per_launch"].get("icp") if single else None) or fam["icp"][0] / fam["icp"][1]
+        if cyc_i and icp_ms:
+            roofline["icp_issue"] = {"kernel": "k_icp", "bound": "valu_issue", "frac": cyc_i / (icp_ms * 1e-3) / SIMD_CYCLES_PER_S, "avg_launch_ms": icp_ms,
+                                     "instructions": pk.get("valu_insts_per_launch"), "cycles_per_instruction": det_i["cycles_per_instruction"],
+                                     "lanes": 1 if single else len(wl.contexts()),
+                                     "note": "SIMD issue cycles per launch (this configuration's instruction-class counters x measured costs; static classes of the three-queries shape) / stand-alone launch duration x 1024 SIMDs x 2.4 GHz"}
     if pmc.get("stale"):
         roofline["stale_pmc"] = pmc["stale"]
     roofline.update({"traffic_source": pmc.get("source"), "avg_launch_ms": alone_ms, "avg_launch_ms_overlapped": avg_ms, "launches": dom_n,
@@ -833,7 +849,7 @@ def other_config_summary(args, res, roofline, parity):
     """What the default line carries of another configuration (bench.py --config <name> prints its full line)."""
     r = {"value": res["wl"].units_per_step * args.steps / res["elapsed"], "unit": "scans/s", "ms_per_step": res["elapsed"] / args.steps * 1e3,
          "steps": args.steps, "warmup": args.warmup, "lanes": len(res["wl"].contexts()), "workload": res["wl"].workload_name(),
-         "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "lanes", "physical", "hbm_algorithmic", "lds_conflict_cycle_share", "chip", "stale_pmc") if k in roofline},
+         "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "lanes", "physical", "hbm_algorithmic", "lds_conflict_cycle_share", "chip", "icp_issue", "stale_pmc") if k in roofline},
          "parity": parity}
     if res["single"]:
         r["single_stream"] = res["single"]
