@@ -46,6 +46,7 @@ _SIGS = {
     "slam_create": ([_i, _vp, C.POINTER(_vp)], _i),
     "slam_destroy": ([_vp], _i),
     "slam_synchronize": ([_vp], _i),
+    "slam_stream_order": ([_vp, _vp, _i], _i),
     "slam_check_status": ([_vp], _i),
     "slam_set_option": ([_vp, C.c_char_p, _d], _i),
     "slam_timing_enable": ([_vp, _i], _i),
@@ -187,6 +188,13 @@ class Context:
 
     def check_status(self):
         check(lib().slam_check_status(self.handle))
+
+    def stream_order(self, stream, direction):
+        """Order this context's work against another HIP stream (``stream``: a raw hipStream_t handle, e.g.
+        ``torch.cuda.current_stream().cuda_stream``) without a host synchronise - ``slam_stream_order``:
+        direction 0 = that stream waits for everything enqueued here so far, 1 = work enqueued here from now on
+        waits for what that stream holds now."""
+        check(lib().slam_stream_order(self.handle, _vp(stream) if stream else None, int(direction)))
 
     def set_option(self, name, value):
         check(lib().slam_set_option(self.handle, name.encode(), float(value)))

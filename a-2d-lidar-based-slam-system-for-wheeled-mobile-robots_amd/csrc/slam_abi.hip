@@ -113,8 +113,7 @@ struct slam_ctx {
     std::vector<hipEvent_t> pev_pose, pev_cast;      // per chunk: "poses written" (main -> pstream), "ray cast done" (pstream -> main)
     hipEvent_t pev_join = nullptr;
     bool pdirty = false;                             // ray casts on pstream the main stream has not waited for
-    int p_last_P = 0, p_last_chunks = 0;             // shape of the batch whose casts may still be running: the next batch of the
-    const void *p_last_poses = nullptr;              //   same shape waits chunk by chunk, any other joins first
+    hipEvent_t ev_order = nullptr;                   // slam_stream_order: ordering with a caller's stream
 };
 
 struct slam_grid {
@@ -258,7 +257,6 @@ int join_particles(slam_ctx *c)
     HIPCHK(hipEventRecord(c->pev_join, c->pstream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->pev_join, 0));
     c->pdirty = false;
-    c->p_last_chunks = 0;
     return SLAM_OK;
 }
 
@@ -459,6 +457,7 @@ int slam_destroy(slam_ctx *c)
         for (double *t : c->pipe_T)
             if (t) (void)hipFree(t);
     }
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->staging.base) (void)hipFree(c->staging.base);
@@ -476,6 +475,32 @@ int slam_synchronize(slam_ctx *c)
     TRY(use(c));
     TRY(join_from_grid(c));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int slam_stream_order(slam_ctx *c, void *stream, int direction)
+{
+    TRY(use(c));
+    REQUIRE(direction == 0 || direction == 1, "direction is 0 (the stream waits for the context) or 1 (the context waits for the stream)");
+    hipStream_t other = static_cast<hipStream_t>(stream);
+    if (!c->ev_order) HIPCHK(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+    if (direction == 0) {
+        TRY(join_from_grid(c));                    // the map / pose / particle streams into the context's stream first
+        if (other == c->stream) return SLAM_OK;
+        HIPCHK(hipEventRecord(c->ev_order, c->stream));
+        HIPCHK(hipStreamWaitEvent(other, c->ev_order, 0));
+        return SLAM_OK;
+    }
+    if (other != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_order, other));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_order, 0));
+    }
+    // with the "pipeline" option the map stage runs on a stream of its own: it forks from the context's stream again before
+    // its next piece of work (as after any map work on the context's stream)
+    if (c->pipeline) {
+        TRY(join_from_grid(c));
+        c->mgrid = true;
+    }
     return SLAM_OK;
 }
 
@@ -1304,17 +1329,10 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
             c->pev_pose.push_back(e0);
             c->pev_cast.push_back(e1);
         }
-        // casts of an earlier batch may still read poses_out / the heading scratch: a batch of the same shape waits for
-        // them chunk by chunk (below), any other waits for all of them
-        if (c->pdirty && (c->p_last_P != P || c->p_last_chunks != chunks || c->p_last_poses != poses_out)) TRY(join_particles(c));
     }
     double *heading_cs = nullptr;               // cos / sin of the new headings: written by the pose step, read by the ray cast
     if (grid) {
         const size_t need = align_up((size_t)P * 16) + 1024;
-        if (need > c->scratch.cap && c->pstream) {   // (the arena is about to be re-allocated: nothing may still read it)
-            TRY(join_particles(c));
-            HIPCHK(hipStreamSynchronize(c->pstream));
-        }
         TRY(arena_reserve(c, c->scratch, need));
         heading_cs = carve<double>(c->scratch, (size_t)P * 2);
         grid->pristine = false;
@@ -1336,8 +1354,6 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
             Timed t(c, SLAM_K_ICP, nullptr, k == 0);
             HIPCHK(launch_icp(a, dtype, c->stream));
         }
-        if (chunks > 1 && c->pdirty && c->p_last_chunks == chunks)      // the previous batch's cast of this chunk has read poses / headings
-            HIPCHK(hipStreamWaitEvent(c->stream, c->pev_cast[k], 0));
         {
             Timed t(c, SLAM_K_COMPOSE, nullptr, k == 0);
             HIPCHK(launch_pose_compose(T_out + 9 * (size_t)p0, pose_prev + 3 * (size_t)p0, pc, 1, poses_out + 3 * (size_t)p0, c->stream,
@@ -1361,8 +1377,13 @@ int slam_particles_dev(slam_ctx *c, const float *ranges2, const double *cos_t, c
         }
     }
     if (chunks > 1) {
+        // The ray casts on the second stream read the caller's ranges2 / cos_t / sin_t / poses_out and the heading scratch: the
+        // context's stream waits for them here, so that - as for every *_dev entry point - work enqueued behind this call is
+        // ordered behind ALL of it (a caller overwriting ranges2 for the next scan pair, slam_replay_dev carving
+        // the same scratch).  The overlap this option is for is the one INSIDE a batch: cast of chunk k beside the matcher of k + 1.
         c->pdirty = true;
-        c->p_last_P = P; c->p_last_chunks = chunks; c->p_last_poses = poses_out;
+        TRY(join_particles(c));
+        if (c->pipeline) c->mgrid = true;      // map work the map stream has not seen: its next piece forks from the main stream
     }
     return SLAM_OK;
 }

@@ -88,13 +88,29 @@ def all_reduce_counters(pass_cnt, hit_cnt, device=None):
 
 def all_reduce_grid(grid):
     """Merge the maps that the ranks built from disjoint scans: one in-place RCCL
-    ``all_reduce(SUM)`` per counter array, on the device (``grid``: a :class:`DeviceGrid`)."""
+    ``all_reduce(SUM)`` per counter array, on the device (``grid``: a :class:`DeviceGrid`).
+
+    Stream ordering (no host synchronise): the collectives are ordered on torch's CURRENT stream, the counters are
+    produced on the grid's context's streams (its own, non-blocking, unless the context was created on torch's).
+    ``slam_stream_order`` makes torch's stream wait for every update the context has enqueued so far - an asynchronous
+    ``DeviceReplay.run()`` included - and afterwards makes the context wait for the collectives before its next update
+    (``dist.all_reduce`` without ``async_op`` returns with torch's current stream ordered behind RCCL's).
+    Runs with any initialised process group, a world of one rank included (the collectives are then the identity; the
+    ordering is the same) - tests/test_gpu_rccl.py does that on the one GPU of the test box."""
+    import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     p, h = grid.counters_torch()
+    if not p.is_cuda:                       # (gloo rehearsals hand in host tensors: nothing to order)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        return
+    cur = torch.cuda.current_stream(p.device).cuda_stream
+    grid._ctx.stream_order(cur, 0)
     dist.all_reduce(p, op=dist.ReduceOp.SUM)
     dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    grid._ctx.stream_order(cur, 1)
 
 
 def hip_runner(ranges, angle_min, angle_max, max_iter, tolerance, local_rank, maps=None):

@@ -107,22 +107,27 @@ def parse():
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
     ap.add_argument("--icp-qpt", type=int, default=None, help="scan-matching queries per lane (default: 3 with several lanes, else the library's choice by batch size)")
     ap.add_argument("--lanes", type=int, default=None, help="contexts (stream sets) the replays alternate between")
+    ap.add_argument("--traj", type=int, default=None,
+                    help="replay / dense: independent replays of the trajectory per slam_replay_dev call (ranges [L, n_scan, n], a map per "
+                         "trajectory); a step is then L replays")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1: map stage of a replay on a second stream, overlapping the next replay's scan matching")
     ap.add_argument("--gather", default="end", choices=["step", "end", "none"],
                     help="N > 1: all_gather of final poses after every replay (async), once at the end, or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of the CPU baseline (it runs FIRST, before any GPU leg)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run comparison with the oracle")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the one-lane repeat of the measurement")
     ap.add_argument("--no-other-configs", action="store_true", help="default config only: skip the brief particles / dense runs behind it")
-    ap.add_argument("--sustain-seconds", type=float, default=0.5)
+    ap.add_argument("--sustain-seconds", type=float, default=None,
+                    help="length of the sustained continuation behind the K steps (default: 3 s for the headline replay configuration, so that "
+                         "a 5-second utilisation sampler sees the GPU busy; 0.5 s for every other measurement)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the parity block is always on)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
+    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes", "traj"):
         if getattr(args, k) is None:
-            setattr(args, k, cfg[k])
+            setattr(args, k, cfg.get(k, 1))
     if args.scans is None:
         # configs[3] (N > 1) names 5k-scan trajectories, configs[1] / [4] a 1k-scan replay
         args.scans = 5000 if (args.gpus > 1 and args.config == "replay") else cfg["scans"]
@@ -132,6 +137,8 @@ def parse():
         # at least one untimed step per lane: a lane's first step allocates its workspaces (hundreds of MB for the dense
         # configuration's ray records) and loads its kernels
         args.warmup = 5 if args.config == "replay" else max(2, args.lanes)
+    if args.sustain_seconds is None:
+        args.sustain_seconds = 3.0 if (args.config == "replay" and args.gpus == 1) else 0.5
     if args.grid_group < 0:
         args.grid_group = 0       # the library's choice (8 scans per ray-cast workgroup for a 1 000-scan replay; with the
                                   # direction halves that beats the 12 which round 1 used when replays overlap: 8.5 vs 8.1 M)
@@ -177,6 +184,28 @@ def cpu_baseline_replay(rep, args, budget_s):
     return {"value": (n - 1) * reps / t_used, "unit": "scans/s", "cores": threads, "kind": "port",
             "sample": "first %d scans of the %d-scan replay x %d repeats (%.1f s), C port of the reference, OpenMP over scan pairs%s"
                       % (n, rep.ranges.shape[0], reps, t_used, " and rays" if args.points == "f64" else "; map cast sequentially")}
+
+
+class _ParticleInputs:
+    """The particle workload's host-side inputs (the CPU baseline runs before any GPU object exists)."""
+    def __init__(self, slam, args, rank):
+        self.P = args.particles
+        self.rep = slam.synthetic.make_replay(2, args.beams, seed=2 + rank, stride=args.stride)
+        self.mats = slam.prior_matrices(slam.synthetic.particle_priors(self.P, seed=2 + rank))
+        self.pose_prev = np.zeros((self.P, 3)) if not args.pose_spread else np.random.default_rng(4 + rank).normal(0, args.pose_spread, size=(self.P, 3))
+
+
+def replay_seed(args, rank):
+    return (10 + rank) if args.gpus > 1 and args.config == "replay" else CONFIGS[args.config]["seed"] + rank
+
+
+def cpu_baseline_first(slam, args, rank):
+    """The CPU baseline of --config from freshly generated inputs (same seeds as the GPU workload), BEFORE any GPU leg: the
+    process then ends on its GPU work instead of twelve seconds of host threads."""
+    if args.config == "particles":
+        return cpu_baseline_particles(_ParticleInputs(slam, args, rank), args, args.cpu_seconds)
+    rep = slam.synthetic.make_replay(args.scans, args.beams, seed=replay_seed(args, rank), room_scale=args.room_scale, stride=args.stride)
+    return cpu_baseline_replay(rep, args, args.cpu_seconds)
 
 
 def cpu_baseline_particles(wl, args, budget_s):
@@ -288,9 +317,14 @@ class ReplayWorkload:
 
     def __init__(self, slam, torch, args, rank, local, n_lanes, slots):
         self.slam, self.torch, self.args = slam, torch, args
-        seed = (10 + rank) if args.gpus > 1 and args.config == "replay" else CONFIGS[args.config]["seed"] + rank
+        seed = replay_seed(args, rank)
         self.rep = slam.synthetic.make_replay(args.scans, args.beams, seed=seed, room_scale=args.room_scale, stride=args.stride)
         self.seed = seed
+        # --traj L: L independent replays of the trajectory per slam_replay_dev call (ranges [L, n_scan, n], trajectory l
+        # into map l of the grid object): one scan-matching launch of L x (n_scan - 1) pairs, one ray-cast launch, L chains of
+        # pose composition side by side.  Pairs are independent (W12m/slam_ekf.py:109-113), so nothing changes per trajectory.
+        self.traj = L = max(1, int(getattr(args, "traj", 1) or 1))
+        ranges = self.rep.ranges if L == 1 else np.ascontiguousarray(np.broadcast_to(self.rep.ranges[None], (L,) + self.rep.ranges.shape))
 
         class Lane:
             pass
@@ -299,10 +333,10 @@ class ReplayWorkload:
             ln = Lane()
             ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
             with torch.cuda.stream(ln.stream):
-                ln.dr = slam.DeviceReplay(self.rep.ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
-                                          dtype=args.points, device=local)
-                ln.grid = ln.dr.make_grid(1, args.grid, args.grid, args.reso)
-                ln.pmap = torch.empty((args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
+                ln.dr = slam.DeviceReplay(ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
+                                          dtype=args.points, device=local, grid_of_traj=np.arange(L) if L > 1 else None)
+                ln.grid = ln.dr.make_grid(L, args.grid, args.grid, args.reso)
+                ln.pmap = torch.empty((L, args.grid, args.grid), dtype=torch.int8, device=ln.dr.dev)
                 ln.ring_T = torch.empty((2,) + tuple(ln.dr.T.shape), dtype=torch.float64, device=ln.dr.dev)
             ln.dr.ctx.set_option("grid_mode", args.grid_mode)
             ln.dr.ctx.set_option("grid_group", args.grid_group)
@@ -349,16 +383,33 @@ class ReplayWorkload:
         ln = self.last_lane()
         poses, T, iters = ln.dr.results()
         self.iters = iters
-        self.visits = ln.grid.visits()          # in-bounds cell visits of the last step (reset every step)
-        dev = {"poses": poses[0], "T": T[0], "iters": iters[0], "visits": self.visits, "pmap": ln.pmap.cpu().numpy()}
-        dev.update(ln.grid.read(0, want=("pass", "hit")))
+        self.visits = ln.grid.visits()          # in-bounds cell visits of the last step, all its maps (reset every step)
+        pm = ln.pmap.cpu().numpy()
+        dev = []                                # one block per trajectory of the step
+        for l in range(self.traj):
+            d = {"poses": poses[l], "T": T[l], "iters": iters[l], "pmap": pm[l]}
+            d.update(ln.grid.read(l, want=("pass", "hit")))
+            dev.append(d)
         return dev
 
     def parity(self, dev):
+        """EVERY trajectory of the last step against the oracle (the L trajectories of a step replay the same scans: the
+        reference is solved once); visits: the step's total against L x the reference's."""
         from oracle import checks
         a = self.args
-        return checks.compare_replay(dev, self.rep.ranges, AMIN, AMAX, a.grid, a.grid, a.reso, a.points, a.max_iter, a.tol,
-                                     threads=cpu_threads())
+        ref = checks.replay_reference_results(self.rep.ranges, AMIN, AMAX, a.grid, a.grid, a.reso, a.points, a.max_iter, a.tol,
+                                              threads=cpu_threads())
+        out = None
+        for d in dev:
+            o = checks.compare_replay_with(d, ref)
+            if out is None:
+                out = o
+            else:
+                for k, v in o.items():
+                    out[k] = (out[k] and v) if isinstance(v, bool) else (max(out[k], v) if k.endswith("_err") else (v if k == "scans" else out[k] + v))
+        out["trajectories_checked"] = len(dev)
+        out["visits_equal"] = bool(int(self.visits) == len(dev) * int(ref["visits"]))
+        return out
 
     def algorithmic_bytes(self):
         a = self.args
@@ -373,8 +424,12 @@ class ReplayWorkload:
     def workload_name(self):
         a = self.args
         which = "configs[3] share" if a.gpus > 1 and a.config == "replay" else ("configs[4]" if a.config == "dense" else "configs[1]")
-        return ("%s: %d-scan replay (every %dth message of a 10 Hz stream, seed %d), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid, %s point buffers"
+        name = ("%s: %d-scan replay (every %dth message of a 10 Hz stream, seed %d), %d beams, ICP(max_iter=%d, tol=%g) + %dx%d@%.2fm grid, %s point buffers"
                 % (which, a.scans, a.stride, self.seed, a.beams, a.max_iter, a.tol, a.grid, a.grid, a.reso, a.points))
+        if self.traj > 1:
+            name += "; %d independent replays of the %d-scan trajectory per step (one slam_replay_dev call: ranges [%d, %d, %d], a map per trajectory)" % (
+                self.traj, a.scans, self.traj, a.scans, a.beams)
+        return name
 
     def cpu_baseline(self, budget):
         return cpu_baseline_replay(self.rep, self.args, budget)
@@ -508,10 +563,12 @@ def config_args(base, name):
     a.config = name
     for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
         setattr(a, k, cfg[k])
+    a.traj = cfg.get("traj", 1)
     a.scans = cfg["scans"]
     a.steps, a.warmup = (48, 5) if name == "replay" else (12, max(2, cfg["lanes"]))   # every lane warms up before the timed region
-    a.grid_group = 0
+    a.grid_group = cfg.get("grid_group", 0)
     a.icp_qpt = None
+    a.sustain_seconds = 0.5
     return a
 
 
@@ -815,7 +872,7 @@ def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, wor
         "config": {"workload": workload, "name": args.config,
                    "units_per_step_per_gpu": units_per_step, "point_buffers": args.points,
                    "point_buffers_note": "storage type of the points the scan matcher sees (arithmetic is float64 either way)",
-                   "pipeline": args.pipeline, "lanes": lanes, "grid_mode": args.grid_mode, "grid_group": args.grid_group,
+                   "pipeline": args.pipeline, "lanes": lanes, "trajectories_per_step": getattr(args, "traj", 1), "grid_mode": args.grid_mode, "grid_group": args.grid_group,
                    "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
         "roofline": roofline,
     }
@@ -917,6 +974,7 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     env = Env(slam, torch, dist, rank, world, local, use_dist)
+    cpu = cpu_baseline_first(slam, args, rank) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     res = measure(args, env, want_single=not args.no_single_stream and not use_dist, want_sustained=not use_dist)
     wl = res["wl"]
     n_ranks = dist.get_world_size() if use_dist else 1
@@ -924,7 +982,7 @@ def main():
 
     if args.no_timing:
         if rank == 0:
-            print(json.dumps({"value": value, "ms_per_step": res["elapsed"] / args.steps * 1e3, "lanes": args.lanes,
+            print(json.dumps({"value": value, "ms_per_step": res["elapsed"] / args.steps * 1e3, "lanes": args.lanes, "traj": args.traj,
                               "pipeline": args.pipeline, "note": "experiment without HIP-event timing"}), flush=True)
         if use_dist:
             dist.destroy_process_group()
@@ -934,7 +992,6 @@ def main():
         res["single"] = same_single          # stand-alone kernel durations of the same workload: roofline.frac keeps its meaning under a process group
     roofline = roofline_of(args, res)
     parity = wl.parity(res["dev_results"]) if rank == 0 and not args.no_parity else None
-    cpu = wl.cpu_baseline(args.cpu_seconds) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     single, sustained = res["single"], res["sustained"]
 
     # ---- the other single-GPU configurations of BASELINE.json, briefly, in the same process (outside every timed region
@@ -968,6 +1025,32 @@ def main():
                     r3["wl"].close()
                     del r3
             except Exception as e:                      # the headline line must not die of a secondary configuration
+                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        # configs[1] again, (a) at the W7 launch file's scan-matching parameters (SURVEY.md 8d asks for both sets: W7_Dead Reckoning
+        # (ICP)/course_agv_slam/launch/icp.launch:10-12 sets max_iter 10, tolerance 0 - every pair runs exactly ten iterations),
+        # (b) as rounds 1-4 measured it: ONE trajectory per call on four overlapping contexts
+        for name, change in (("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes)),
+                             ("lanes4_single_trajectory", dict(traj=1, lanes=4, grid_group=0, steps=48, warmup=5))):
+            a4 = argparse.Namespace(**vars(args))
+            for k, v in change.items():
+                setattr(a4, k, v)
+            a4.sustain_seconds = 0.5
+            try:
+                r4 = measure(a4, env, want_single=(name == "replay_w7_params"), want_sustained=True)
+                w4 = r4["wl"]
+                o4 = {"value": w4.units_per_step * a4.steps / r4["elapsed"], "unit": "scans/s", "ms_per_step": r4["elapsed"] / a4.steps * 1e3, "steps": a4.steps,
+                      "warmup": a4.warmup, "lanes": len(w4.contexts()), "trajectories_per_step": a4.traj, "workload": w4.workload_name(),
+                      "sustained": {k: r4["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")} if r4["sustained"] else None,
+                      "kernel_ms_per_launch_overlapped": {k: v[0] / v[1] for k, v in r4["fam"].items() if v[1] > 0},
+                      "mean_iters": float(np.asarray(r4["dev_results"][0]["iters"]).mean()),
+                      "parity": None if args.no_parity else w4.parity(r4["dev_results"])}
+                if r4["single"]:
+                    o4["single_stream"] = r4["single"]
+                others[name] = o4
+                w4.close()
+                del r4, w4
+            except Exception as e:
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
         wl_name, units, lanes = res["workload_name"], res["units"], res["lanes"]

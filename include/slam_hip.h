@@ -69,10 +69,21 @@ const char *slam_last_error(void);
 int slam_create(int device, void *stream, slam_ctx **out);
 int slam_destroy(slam_ctx *ctx);
 int slam_synchronize(slam_ctx *ctx);
+/* Order the context's work against another HIP stream of the caller WITHOUT a host synchronise (stream: a
+ * hipStream_t, e.g. torch's current stream, on which the RCCL collectives of torch.distributed are ordered; NULL: the
+ * legacy default stream).  direction 0: `stream` waits for everything this context has enqueued so far - on its own
+ * stream and on its internal ones ("pipeline" map / pose stages, chunked particle ray casts); direction 1: everything
+ * the context enqueues from now on waits for what `stream` holds at this moment.  The reference has no counterpart
+ * (one Python thread, W12m/slam_ekf.py:63-95); this is what makes a device pointer handed out by
+ * slam_grid_counters_dev / slam_grid_live_pmap safe to use from a stream the library does not own:
+ *   slam_grid_counters_dev(...); slam_stream_order(ctx, s, 0); <all_reduce on s>; slam_stream_order(ctx, s, 1); */
+int slam_stream_order(slam_ctx *ctx, void *stream, int direction);
 /* Synchronise and return-and-clear the sticky data error raised by kernels since the
  * last call (SLAM_OK, SLAM_ERR_NAN or SLAM_ERR_OVERFLOW). */
 int slam_check_status(slam_ctx *ctx);
-/* Tuning knobs (results never depend on them).
+/* Tuning knobs.  Maps, cell indices, nearest-neighbour indices and iteration counts never depend on them; the launch
+ * shape of the scan matcher ("icp_qpt", and the batch size itself) decides the order in which a pair's sums are added,
+ * so transforms and poses of two shapes agree to rounding (1e-13), not bit for bit.
  * "grid_mode": 1 = automatic (default): ray casting through an LDS window per group of scans,
  *   or - for one shared map much larger than a window - rays dealt by direction and swept in
  *   bands through a sheared window (wedges); 0 = direct global atomics; 2 = walks recorded once
@@ -99,7 +110,12 @@ int slam_check_status(slam_ctx *ctx);
  *   next; give consecutive replays different poses_out and T_out buffers to benefit (a buffer an
  *   earlier stage is still reading is waited for).  Results of the later stages (poses_out,
  *   pmap_dev) are visible after slam_synchronize / a device synchronise, or to any later call
- *   on this context.  0 = everything on the context's stream (default). */
+ *   on this context.  0 = everything on the context's stream (default).
+ * "particle_chunks": k > 1 = slam_particles_dev cuts its batch into k chunks: scan matching and pose step of chunk
+ *   i + 1 on the context's stream beside the ray cast of chunk i on a second stream.  The call still returns with the
+ *   context's stream ordered behind ALL of its work (the second stream is joined at the end), so buffers may be
+ *   reused by later calls as with any *_dev entry point.  Measured slower than one piece on MI355X;
+ *   0 / 1 = off (default). */
 int slam_set_option(slam_ctx *ctx, const char *name, double value);
 /* Per-kernel-family timing with HIP events on the context's stream (bench.py roofline).
  * on: 0 = off, 1 = every family, 2 * mask = only the families in mask (bit SLAM_K_*): events on a
@@ -204,7 +220,10 @@ int slam_grid_read(slam_ctx *ctx, slam_grid *grid, int g, int8_t *pmap, double *
  * checkpoint / restore and for merging maps that several GPUs built from disjoint scans - one
  * all_reduce(SUM) over the ranks, in place (integer sums commute, so the merged map is
  * bit-identical for any rank count).  Work enqueued on the context's stream after
- * this call sees every earlier update; a live pmap is marked stale. */
+ * this call sees every earlier update; a live pmap is marked stale.  The call orders nothing against
+ * OTHER streams: a consumer on a stream of its own (a collective on torch's current stream) first makes
+ * that stream wait for the context, and the context wait for it afterwards, with slam_stream_order -
+ * dist.all_reduce_grid of the Python package does exactly that. */
 int slam_grid_counters_dev(slam_ctx *ctx, slam_grid *grid, uint32_t **pass_dev, uint32_t **hit_dev);
 
 /* Keep pmap [G][xw][yw] int8 resident and current on the device and return its address.

@@ -52,22 +52,35 @@ def replay_reference(ranges, amin, amax, grid, points="f64", max_iter=30, tol=1e
     return poses, T, it, visits
 
 
-def compare_replay(dev, ranges, amin, amax, xw, yw, reso, points="f64", max_iter=30, tol=1e-3, threads=None):
-    """dev: dict with the device's 'poses' [n-1,3], 'T' [n-1,3,3], 'iters' [n-1] and optionally
-    'pass', 'hit', 'pmap' [xw,yw], 'visits'."""
-    og = metric_grid(xw, yw, reso) if "pass" in dev else None
+def replay_reference_results(ranges, amin, amax, xw, yw, reso, points="f64", max_iter=30, tol=1e-3, threads=None, with_grid=True):
+    """The reference's answers for one trajectory as a dict (poses, T, iters, visits and - with_grid - the oracle Grid),
+    for compare_replay_with: a step of several replays of the same scans solves the reference once."""
+    og = metric_grid(xw, yw, reso) if with_grid else None
     poses, T, it, visits = replay_reference(ranges, amin, amax, og, points, max_iter, tol, threads=threads)
+    return {"poses": poses, "T": T, "iters": it, "visits": visits, "grid": og}
+
+
+def compare_replay_with(dev, ref):
+    """dev: dict with the device's 'poses' [n-1,3], 'T' [n-1,3,3], 'iters' [n-1] and optionally
+    'pass', 'hit', 'pmap' [xw,yw], 'visits'; ref: replay_reference_results(...)."""
+    poses, T, it, og = ref["poses"], ref["T"], ref["iters"], ref["grid"]
     out = {"scans": int(len(it)),
            "pose_max_abs_err": float(np.max(np.abs(np.asarray(dev["poses"]) - poses))),
            "T_max_abs_err": float(np.max(np.abs(np.asarray(dev["T"]).reshape(T.shape) - T))),
            "iters_equal": bool(np.array_equal(np.asarray(dev["iters"]).reshape(-1), it))}
-    if og is not None:
+    if og is not None and "pass" in dev:
         out["counter_cell_mismatches"] = int(np.sum(dev["pass"] != og.pass_cnt) + np.sum(dev["hit"] != og.hit_cnt))
         if "pmap" in dev:
             out["pmap_cell_mismatches"] = int(np.sum(dev["pmap"] != og.pmap))
         if "visits" in dev:
-            out["visits_equal"] = bool(int(dev["visits"]) == int(visits))
+            out["visits_equal"] = bool(int(dev["visits"]) == int(ref["visits"]))
     return out
+
+
+def compare_replay(dev, ranges, amin, amax, xw, yw, reso, points="f64", max_iter=30, tol=1e-3, threads=None):
+    """One trajectory's device results against the reference solved here (see compare_replay_with)."""
+    return compare_replay_with(dev, replay_reference_results(ranges, amin, amax, xw, yw, reso, points, max_iter, tol, threads=threads,
+                                                             with_grid="pass" in dev))
 
 
 def particle_reference(ranges_prev, ranges_cur, amin, amax, prior_mat, pose_prev, xw, yw, reso, max_iter=30, tol=1e-3):

@@ -1,0 +1,98 @@
+"""Child process of tests/test_gpu_rccl.py::test_shared_map_merge_is_stream_ordered_under_rccl (not collected by pytest:
+no test_ prefix).  Started by `python -m torch.distributed.run --nproc-per-node 1`, so RANK / WORLD_SIZE / MASTER_* are
+set and the process group below is a real RCCL communicator with a world of one rank.
+
+What it checks (the shared-map case; W12m/mapping.py:42-50: additive evidence, so integer counters of
+maps built from disjoint scans add up to the map built from all of them):
+ 1. two maps built from DISJOINT halves of a trajectory by an ASYNCHRONOUS DeviceReplay.run() on a context whose stream is
+    not torch's current stream, dist.all_reduce_grid() immediately behind it (no host synchronise in between), then - on
+    torch's current stream, where the collectives ran - map 0 + map 1 == the counters of ONE map built from the whole
+    trajectory;
+ 2. the other direction of the ordering: a late write to the counters on torch's stream (behind a long sleep kernel - what
+    a slow collective looks like), slam_stream_order(direction 1), slam_grid_reset on the context: the reset must come last;
+ 3. (informational) the same read as in 1 WITHOUT the ordering call sees counters the ray cast has not finished writing -
+    what dist.all_reduce_grid did until round 5.
+Prints one JSON line."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "a-2d-lidar-based-slam-system-for-wheeled-mobile-robots_amd"
+AMIN, AMAX = -3.14159, 3.14159
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    slam = importlib.import_module(PKG)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    saved = os.dup(1)                      # RCCL's banner goes to stderr: stdout carries the ONE JSON line
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    h = 1000
+    rep = slam.synthetic.make_replay(2 * h + 1, 360, seed=5)
+    out = {"world": dist.get_world_size(), "backend": dist.get_backend()}
+
+    # the whole trajectory into ONE map, synchronously: the answer
+    dr1 = slam.DeviceReplay(rep.ranges, AMIN, AMAX, device=local)
+    g1 = dr1.make_grid(1, 400, 400, 0.05)
+    dr1.run()
+    poses = dr1.results()[0][0]                                   # [2h, 3]: pose of scan k + 1 at row k
+    ref = g1.read(0, want=("pass", "hit"))
+    ref_p = torch.from_numpy(ref["pass"].astype(np.int64)).cuda()
+    ref_h = torch.from_numpy(ref["hit"].astype(np.int64)).cuda()
+
+    # two maps from disjoint halves: trajectory 0 = scans 0..h from the origin, trajectory 1 = scans h..2h from the pose of
+    # scan h; a context on a side stream, so that the collectives (torch's current stream) run on ANOTHER stream
+    side = torch.cuda.Stream(device=local)
+    halves = np.stack([rep.ranges[: h + 1], rep.ranges[h:]])
+    with torch.cuda.stream(side):
+        dr2 = slam.DeviceReplay(halves, AMIN, AMAX, device=local, pose0=np.stack([np.zeros(3), poses[h - 1]]), grid_of_traj=[0, 1])
+        g2 = dr2.make_grid(2, 400, 400, 0.05)
+    cur = torch.cuda.current_stream(local)
+    assert cur.cuda_stream != side.cuda_stream
+
+    # 3. (control, first: it must not profit from an earlier synchronise) unordered read right behind the asynchronous run
+    dr2.run()
+    p, hh = g2.counters_torch()
+    early = (p.sum(0).to(torch.int64) - ref_p).abs().sum() + (hh.sum(0).to(torch.int64) - ref_h).abs().sum()
+    dr2.ctx.synchronize()
+    torch.cuda.synchronize()
+    out["unordered_read_mismatches"] = int(early.item())
+
+    # 1. asynchronous run, merge immediately behind it, read on torch's stream
+    dr2.run()                                                     # (resets the maps first: option replay_reset)
+    slam.dist.all_reduce_grid(g2)
+    p, hh = g2.counters_torch()
+    bad = (p.sum(0).to(torch.int64) - ref_p).abs().sum() + (hh.sum(0).to(torch.int64) - ref_h).abs().sum()
+    out["merged_counter_mismatches"] = int(bad.item())
+    out["cells_touched"] = int((ref_p + ref_h > 0).sum().item())
+
+    # 2. the context waits for torch's stream
+    torch.cuda._sleep(int(3e8))                                   # ~0.15 s of torch's stream
+    p.fill_(7)
+    dr2.ctx.stream_order(cur.cuda_stream, 1)
+    g2.reset()
+    dr2.ctx.synchronize()
+    torch.cuda.synchronize()
+    out["reset_came_last"] = bool(int(p.abs().max().item()) == 0)
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

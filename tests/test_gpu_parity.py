@@ -912,7 +912,8 @@ def test_icp_clouds_far_from_the_origin_one_pass_products(slam, syn, n, offset):
 def test_particle_batch_in_chunks_is_identical(slam, syn):
     """Context option "particle_chunks": the batch is cut into chunks whose ray casts run on a second stream behind the
     next chunk's scan matching.  Hypotheses are independent, so poses, transforms, iteration counts and every map must
-    equal the one-piece batch bit for bit - also when a second batch follows while the first one's casts may still run."""
+    equal the one-piece batch bit for bit, a second batch into settled maps included.  (The host-pointer path synchronises
+    between batches; the device path without any host synchronise is the next test.)"""
     rep = syn.make_replay(2, 360, seed=2, stride=5)
     P = 50
     mats = slam.prior_matrices(syn.particle_priors(P, seed=8))
@@ -935,3 +936,70 @@ def test_particle_batch_in_chunks_is_identical(slam, syn):
         for p in range(P):
             for k in ("pmap", "pass", "hit"):
                 assert np.array_equal(a[3][p][k], b[3][p][k]), (chunks, p, k)
+
+
+@pytest.mark.parametrize("chunks,pipeline", [(3, 0), (4, 1), (2, 1)])
+def test_particles_dev_back_to_back_without_host_sync(slam, syn, chunks, pipeline):
+    """with "particle_chunks" > 1 the ray casts of a batch run on a second stream and read the CALLER's buffers
+    (ranges2, trig tables, poses_out) and the context's heading scratch.  slam_particles_dev is a *_dev entry point: work
+    enqueued behind it must be ordered behind all of it.  Here, with NO host synchronise anywhere between the calls:
+    batch 1 on scan pair (0, 1) -> ranges2 overwritten on the context's stream with pair (1, 2) -> a slam_replay_dev with
+    T_out == NULL (it carves the same scratch arena the headings live in) -> batch 2 on the new pair from batch 1's poses
+    into the same maps.  Everything - both batches' poses, transforms, iteration counts, every map - must equal the
+    one-piece, one-stream run bit for bit (hypotheses are independent: ICP.process / Mapping.update per hypothesis)."""
+    import torch
+    A = slam._abi
+    L = A.lib()
+    rep = syn.make_replay(3, 360, seed=2, stride=5)
+    small = syn.make_replay(40, 360, seed=12, stride=5)
+    P = 60          # (at most 64 pairs a launch, whole or in chunks: one launch shape, so the sums are formed in one order and the floats agree bit for bit)
+    mats = slam.prior_matrices(syn.particle_priors(P, seed=8)).reshape(P, 6)
+    pose_prev = np.random.default_rng(9).normal(0, 0.3, size=(P, 3))
+    ct, sn = A.trig_tables(AMIN, AMAX, 360)
+
+    def run(chunks, pipeline):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            ctx = A.Context(0, st.cuda_stream)
+            ctx.set_option("pipeline", pipeline)
+            ctx.set_option("particle_chunks", chunks)
+            grid = slam.DeviceGrid.metric(P, 400, 400, 0.05, context=ctx)
+            grid.live_pmap()
+            r2, r2_next = d(rep.ranges[0:2].astype(np.float32)), d(rep.ranges[1:3].astype(np.float32))
+            cos_t, sin_t, prior, p0 = d(ct), d(sn), d(mats), d(pose_prev)
+            sm_r, sm_p0 = d(small.ranges.astype(np.float32)[None]), d(np.zeros((1, 3)))
+            sm_poses = torch.empty((1, 39, 3), dtype=torch.float64, device="cuda")
+            o = [dict(poses=torch.empty((P, 3), dtype=torch.float64, device="cuda"), T=torch.empty((P, 9), dtype=torch.float64, device="cuda"),
+                      it=torch.empty(P, dtype=torch.int32, device="cuda")) for _ in range(2)]
+            st.synchronize()
+
+            def batch(k, prev):
+                A.check(L.slam_particles_dev(ctx.handle, r2.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), 360, A.F64, prior.data_ptr(),
+                                             prev.data_ptr(), P, 30, 1e-3, grid._h, None, o[k]["poses"].data_ptr(), o[k]["T"].data_ptr(),
+                                             o[k]["it"].data_ptr()))
+            batch(0, p0)
+            r2.copy_(r2_next)                                        # on the context's stream (= torch's current one here)
+            A.check(L.slam_replay_dev(ctx.handle, sm_r.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), 1, 40, 360, A.F64, 30, 1e-3,
+                                      sm_p0.data_ptr(), None, None, None, sm_poses.data_ptr(), None, None))
+            batch(1, o[0]["poses"])
+            ctx.synchronize()
+            ctx.check_status()
+            res = [{k: v.cpu().numpy() for k, v in ob.items()} for ob in o]
+            res.append(sm_poses.cpu().numpy())
+            maps = [grid.read(p, want=("pmap", "pass", "hit")) for p in range(0, P, 5)]
+            vis = grid.visits()
+            grid.close()
+            ctx.close()
+        return res, maps, vis
+
+    want, wmaps, wvis = run(1, 0)
+    got, gmaps, gvis = run(chunks, pipeline)
+    for k in range(2):
+        for key in ("poses", "T", "it"):
+            assert np.array_equal(want[k][key], got[k][key]), (k, key)
+    assert np.array_equal(want[2], got[2]) and wvis == gvis
+    assert int(want[0]["it"].max()) >= 3 and not np.array_equal(want[0]["poses"], want[1]["poses"])
+    for a, b in zip(wmaps, gmaps):
+        for key in ("pmap", "pass", "hit"):
+            assert np.array_equal(a[key], b[key]), key
