@@ -75,7 +75,11 @@ AMIN, AMAX = -3.14159, 3.14159
 
 CONFIGS = {
     # name: scans, beams, grid, reso, room_scale, points, seed, lanes
-    "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=4),
+    # replay: 16 independent replays of the trajectory per slam_replay_dev call on 2 overlapping contexts, 16 scans per ray-cast
+    # workgroup (profiles/r05_traj_sweep.txt: one 999-pair launch cannot fill the chip - its scan matcher runs 999 pairs in 0.100 ms
+    # alone and in 0.049 ms inside a 16-trajectory launch; rounds 1-4 ran ONE trajectory per call on 4 contexts, kept as
+    # other_configs.lanes4_single_trajectory)
+    "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=2, traj=16, grid_group=16),
     "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=4),
     "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=2),
 }
@@ -102,7 +106,7 @@ def parse():
                     help="storage type of the ICP point buffers (arithmetic is always f64)")
     ap.add_argument("--grid-mode", type=int, default=1, help="1: automatic (LDS window; direction wedges on maps much larger than a window), 0: direct global atomics, 2: recorded walks + tiles, 3: window, 4: wedges")
     ap.add_argument("--grid-group", type=int, default=-1,
-                    help="scans per ray-cast workgroup (0: the library's choice; default: 12 when replays overlap, else 0)")
+                    help="scans per ray-cast workgroup (0: the library's choice; default: the configuration's - 16 for the batched replay, else 0)")
     ap.add_argument("--grid-split", type=int, default=None, choices=[-1, 0, 1], help="window ray cast: two workgroups per group of scans (default: the library's choice for one lane, off when replays overlap)")
     ap.add_argument("--no-timing", action="store_true", help="experiment: no HIP events around the kernels (no roofline)")
     ap.add_argument("--icp-qpt", type=int, default=None, help="scan-matching queries per lane (default: 3 with several lanes, else the library's choice by batch size)")
@@ -125,23 +129,28 @@ def parse():
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the parity block is always on)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes", "traj"):
-        if getattr(args, k) is None:
-            setattr(args, k, cfg.get(k, 1))
     if args.scans is None:
         # configs[3] (N > 1) names 5k-scan trajectories, configs[1] / [4] a 1k-scan replay
         args.scans = 5000 if (args.gpus > 1 and args.config == "replay") else cfg["scans"]
+    if args.traj is None:
+        # about 16 000 scan pairs per scan-matching launch: 16 replays of the 1k-scan trajectory, 3 of a 5k-scan one
+        args.traj = max(1, round(cfg["traj"] * 1000 / args.scans)) if "traj" in cfg else 1
+    for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
     if args.steps is None:
-        args.steps = 48 if args.config == "replay" else 12     # (multiples of the lane counts 4 / 2 / 3: no lane runs a step more than another)
+        args.steps = 20 if args.config == "replay" else 12     # (multiples of the lane counts 2 / 2 / 4: no lane runs a step more than another)
     if args.warmup is None:
         # at least one untimed step per lane: a lane's first step allocates its workspaces (hundreds of MB for the dense
         # configuration's ray records) and loads its kernels
-        args.warmup = 5 if args.config == "replay" else max(2, args.lanes)
+        args.warmup = 4 if args.config == "replay" else max(2, args.lanes)
     if args.sustain_seconds is None:
         args.sustain_seconds = 3.0 if (args.config == "replay" and args.gpus == 1) else 0.5
     if args.grid_group < 0:
-        args.grid_group = 0       # the library's choice (8 scans per ray-cast workgroup for a 1 000-scan replay; with the
-                                  # direction halves that beats the 12 which round 1 used when replays overlap: 8.5 vs 8.1 M)
+        # the library's choice (8 scans per ray-cast workgroup for ONE 1 000-scan replay, 12 from two on) unless the configuration names
+        # one: 16 for the batched replay - 504 workgroups for 8 trajectories, one round on the chip's 512 slots (8 / 12 / 16 / 20 scans:
+        # 0.280 / 0.267 / 0.211 / 0.258 ms per 8 trajectories, profiles/r05_traj_sweep.txt)
+        args.grid_group = cfg.get("grid_group", 0) if args.traj > 1 else 0
     return args
 
 
@@ -565,7 +574,7 @@ def config_args(base, name):
         setattr(a, k, cfg[k])
     a.traj = cfg.get("traj", 1)
     a.scans = cfg["scans"]
-    a.steps, a.warmup = (48, 5) if name == "replay" else (12, max(2, cfg["lanes"]))   # every lane warms up before the timed region
+    a.steps, a.warmup = (20, 4) if name == "replay" else (12, max(2, cfg["lanes"]))   # every lane warms up before the timed region
     a.grid_group = cfg.get("grid_group", 0)
     a.icp_qpt = None
     a.sustain_seconds = 0.5
@@ -728,7 +737,10 @@ def roofline_of(args, res):
     HIP-event time; its duration is the stand-alone one-lane duration wherever one was measured)."""
     wl, fam, single, elapsed = res["wl"], res["fam"], res["single"], res["elapsed"]
     ms = {k: v[0] for k, v in fam.items() if v[1] > 0}
-    dom = max(ms, key=ms.get)
+    # the dominant family: by STAND-ALONE duration where the one-lane repeat measured it (every family is launched once per step;
+    # overlapped durations also count the time a kernel waits for the chip beside the other lanes' kernels)
+    alone = {k: v for k, v in ((single or {}).get("kernel_ms_per_launch") or {}).items() if k in ms}
+    dom = max(alone, key=alone.get) if alone else max(ms, key=ms.get)
     dom_ms, dom_n = fam[dom]
     alg = wl.algorithmic_bytes()
     kname = wl.family_kernels.get(dom, dom)
@@ -737,7 +749,8 @@ def roofline_of(args, res):
     avg_ms = dom_ms / dom_n
     alone_ms = single["kernel_ms_per_launch"].get(dom, avg_ms) if single else avg_ms
     pmc = load_pmc(args.config, kname)
-    profiled_units = CONFIGS[args.config]["scans"] - 1 if args.config != "particles" else wl.units_per_step
+    # (the PMC passes of tools/profile_gpu.sh run the configuration's defaults: scans - 1 pairs x trajectories per launch)
+    profiled_units = (CONFIGS[args.config]["scans"] - 1) * CONFIGS[args.config].get("traj", 1) if args.config != "particles" else wl.units_per_step
     if pmc and wl.units_per_step != profiled_units:
         # the PMC passes ran the configuration's default size: counts per launch scale with the scans per launch
         scale = wl.units_per_step / float(profiled_units)
@@ -873,7 +886,8 @@ def assemble_line(args, n_ranks, value, ms_per_step, enqueue_ms, closing_ms, wor
                    "units_per_step_per_gpu": units_per_step, "point_buffers": args.points,
                    "point_buffers_note": "storage type of the points the scan matcher sees (arithmetic is float64 either way)",
                    "pipeline": args.pipeline, "lanes": lanes, "trajectories_per_step": getattr(args, "traj", 1), "grid_mode": args.grid_mode, "grid_group": args.grid_group,
-                   "parallelism": "1 trajectory per GPU" + (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
+                   "parallelism": "1 trajectory per GPU" + (" (%d independent replays of it per step)" % getattr(args, "traj", 1) if getattr(args, "traj", 1) > 1 else "") +
+                                  (", all_gather of final poses (%s)" % args.gather if use_dist else "")},
         "roofline": roofline,
     }
     if timing_mask is not None:
@@ -918,6 +932,35 @@ def other_config_summary(args, res, roofline, parity):
     if res.get("instrumented"):
         r["instrumented"] = res["instrumented"]
     return r
+
+
+def _replay_legs(args, env, torch, others):
+    """configs[1] again, (a) as rounds 1-4 measured it: ONE trajectory per call on four overlapping contexts, (b) at the W7 launch
+    file's scan-matching parameters (SURVEY.md 8d asks for both sets: W7_Dead Reckoning (ICP)/course_agv_slam/launch/icp.launch:10-12
+    sets max_iter 10, tolerance 0 - every pair runs exactly ten iterations)."""
+    for name, change in (("lanes4_single_trajectory", dict(traj=1, lanes=4, grid_group=0, steps=48, warmup=5)),
+                         ("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes))):
+        a4 = argparse.Namespace(**vars(args))
+        for k, v in change.items():
+            setattr(a4, k, v)
+        a4.sustain_seconds = 0.5
+        try:
+            r4 = measure(a4, env, want_single=(name == "replay_w7_params"), want_sustained=True)
+            w4 = r4["wl"]
+            o4 = {"value": w4.units_per_step * a4.steps / r4["elapsed"], "unit": "scans/s", "ms_per_step": r4["elapsed"] / a4.steps * 1e3, "steps": a4.steps,
+                  "warmup": a4.warmup, "lanes": len(w4.contexts()), "trajectories_per_step": a4.traj, "workload": w4.workload_name(),
+                  "sustained": {k: r4["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")} if r4["sustained"] else None,
+                  "kernel_ms_per_launch_overlapped": {k: v[0] / v[1] for k, v in r4["fam"].items() if v[1] > 0},
+                  "mean_iters": float(np.asarray(r4["dev_results"][0]["iters"]).mean()),
+                  "parity": None if args.no_parity else w4.parity(r4["dev_results"])}
+            if r4["single"]:
+                o4["single_stream"] = r4["single"]
+            others[name] = o4
+            w4.close()
+            del r4, w4
+        except Exception as e:
+            others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -1003,6 +1046,7 @@ def main():
         del res["wl"], wl
         torch.cuda.empty_cache()
         others = {}
+        _replay_legs(args, env, torch, others)
         for name in ("particles", "dense"):
             a2 = config_args(args, name)
             try:
@@ -1025,32 +1069,6 @@ def main():
                     r3["wl"].close()
                     del r3
             except Exception as e:                      # the headline line must not die of a secondary configuration
-                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
-            torch.cuda.empty_cache()
-        # configs[1] again, (a) at the W7 launch file's scan-matching parameters (SURVEY.md 8d asks for both sets: W7_Dead Reckoning
-        # (ICP)/course_agv_slam/launch/icp.launch:10-12 sets max_iter 10, tolerance 0 - every pair runs exactly ten iterations),
-        # (b) as rounds 1-4 measured it: ONE trajectory per call on four overlapping contexts
-        for name, change in (("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes)),
-                             ("lanes4_single_trajectory", dict(traj=1, lanes=4, grid_group=0, steps=48, warmup=5))):
-            a4 = argparse.Namespace(**vars(args))
-            for k, v in change.items():
-                setattr(a4, k, v)
-            a4.sustain_seconds = 0.5
-            try:
-                r4 = measure(a4, env, want_single=(name == "replay_w7_params"), want_sustained=True)
-                w4 = r4["wl"]
-                o4 = {"value": w4.units_per_step * a4.steps / r4["elapsed"], "unit": "scans/s", "ms_per_step": r4["elapsed"] / a4.steps * 1e3, "steps": a4.steps,
-                      "warmup": a4.warmup, "lanes": len(w4.contexts()), "trajectories_per_step": a4.traj, "workload": w4.workload_name(),
-                      "sustained": {k: r4["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")} if r4["sustained"] else None,
-                      "kernel_ms_per_launch_overlapped": {k: v[0] / v[1] for k, v in r4["fam"].items() if v[1] > 0},
-                      "mean_iters": float(np.asarray(r4["dev_results"][0]["iters"]).mean()),
-                      "parity": None if args.no_parity else w4.parity(r4["dev_results"])}
-                if r4["single"]:
-                    o4["single_stream"] = r4["single"]
-                others[name] = o4
-                w4.close()
-                del r4, w4
-            except Exception as e:
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
         wl_name, units, lanes = res["workload_name"], res["units"], res["lanes"]

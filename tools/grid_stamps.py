@@ -47,6 +47,10 @@ def run(L, group, scans, split=None):
     print("L %d, group %d%s: %d workgroups; lifetime mean %.0f k cycles, max %.0f k (%.2f x mean); phases (k cycles, mean): %s"
           % (L, group, "" if split is None else ", split %d" % split, wgs, life.mean() / 1e3, life.max() / 1e3, life.max() / life.mean(),
              ", ".join("%s %.1f" % (n, v / 1e3) for n, v in zip(NAMES, ph.mean(axis=0)))))
+    if int(c[12]):
+        nb = float(c[12])
+        print("     walk per wave-batch of 64 rays (%d batches): set-up %.0f cycles, walk %.0f cycles for %.0f wave-steps (%.1f cycles a step); per workgroup: %.1f batches"
+              % (int(c[12]), c[10] / nb, c[11] / nb, c[13] / nb, float(c[11]) / max(float(c[13]), 1.0), nb / max(wgs, 1)))
     order = np.argsort(-life)[:3]
     for k in order:
         print("     longest: block %d traj %d: %s = %.0f k" % (rec[k, 6] & 0xffff, rec[k, 6] >> 16, " ".join("%.0f" % (v / 1e3) for v in ph[k]), life[k] / 1e3))
