@@ -60,6 +60,46 @@ def test_config4_dense_1080_f16_2000x2000_tiles(slam, syn):
         assert np.array_equal(r["pass"], dev["pass"]) and np.array_equal(r["hit"], dev["hit"]), mode
 
 
+# ------------------------------------------------------------------ configs[1] as bench.py runs it since round 5: batches of trajectories
+@pytest.mark.parametrize("group", [0, 16])
+def test_config1_batch_of_8_trajectories_of_1000_scans(slam, syn, group):
+    """What bench.py's default step is made of: L independent 1 000-scan trajectories in ONE
+    slam_replay_dev call - ranges [L, 1000, 360], trajectory l into map l of the grid object, one scan-matching launch of
+    L x 999 pairs in the full-chip launch shape, L pose chains side by side, one ray-cast launch with 125 / 63 workgroups per
+    trajectory.  Here L = 8 DIFFERENT trajectories (seeds 1..8, different start poses): every trajectory's poses,
+    transforms, iteration counts, counters, pmap and visits against the C oracle run on that trajectory alone (pairs
+    and trajectories are independent: W12m/slam_ekf.py:109-113).  group 0: the library's choice of scans per ray-cast
+    workgroup (12), 16: bench.py's."""
+    L = 8
+    reps = [syn.make_replay(1000, 360, seed=1 + l, stride=5) for l in range(L)]
+    ranges = np.stack([r.ranges for r in reps])
+    p0 = np.zeros((L, 3))
+    p0[1:] = np.random.default_rng(3).normal(0, [0.5, 0.5, 0.7], size=(L - 1, 3))
+    dr = slam.DeviceReplay(ranges, AMIN, AMAX, pose0=p0, grid_of_traj=np.arange(L))
+    grid = dr.make_grid(L, 400, 400, 0.05)
+    dr.ctx.set_option("grid_group", group)
+    dr.run()
+    poses, T, it = dr.results()
+    total = 0
+    for l in range(L):
+        og = checks.metric_grid(400, 400, 0.05)
+        op, oT, oit, ovis = checks.replay_reference(ranges[l], AMIN, AMAX, og, pose0=tuple(p0[l]))
+        assert np.array_equal(it[l], oit), l
+        assert np.max(np.abs(poses[l] - op)) < FTOL and np.max(np.abs(T[l] - oT)) < FTOL, l
+        r = grid.read(l, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), l
+        total += ovis
+    assert grid.visits() == total
+    assert len({int(v.sum()) for v in it}) > 1           # the trajectories really differ
+    # a second pass without reset doubles every counter (integer evidence adds up, mapping.py:42-45)
+    c0 = grid.read(0, want=("pass", "hit"))
+    dr.run(reset_grid=False)
+    c1 = grid.read(0, want=("pass", "hit"))
+    assert np.array_equal(c1["pass"], 2 * c0["pass"]) and np.array_equal(c1["hit"], 2 * c0["hit"])
+    grid.close()
+    dr.ctx.close()
+
+
 # ------------------------------------------------------------------ configs[3] per-GPU share
 def test_config3_share_5000_scan_replay(slam, syn):
     """One rank's share of BASELINE configs[3]: a 5 000-scan trajectory (seed 10 = rank 0's),
