@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <climits>
 #include <type_traits>
 
@@ -1744,6 +1747,27 @@ __global__ void __launch_bounds__(THREADS, (kOwn8PerCU * THREADS + 255) / 256) k
     lds_guard_check(guard, g.status);
 }
 
+// CUs and LDS bytes per CU of the current device (cached per device): the launch shapes below count workgroups against them
+struct ChipShape { int cus; long lds_per_cu; };
+static ChipShape chip_shape()
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, ChipShape>> seen;
+    int dev = 0;
+    ChipShape c{256, 160 * 1024};                                    // MI355X, should a query fail
+    if (hipGetDevice(&dev) != hipSuccess) return c;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &e : seen)
+        if (e.first == dev) return e.second;
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) c.cus = v;
+    // (gfx950 reports 160 KiB here; a workgroup may ask for all of it)
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) c.lds_per_cu = v;
+    (void)hipGetLastError();
+    seen.push_back({dev, c});
+    return c;
+}
+
 template <class Src>
 static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans, int n, int group, const int32_t *got,
                              hipStream_t s, int split_pref = -1)
@@ -1791,17 +1815,21 @@ static hipError_t launch_win(const GridDev &g, const Src &src, int L, int scans,
         else                    SLAM_LAUNCH((k_grid_update_owner<Src, 2>), dim3(1, L), dim3(kOwnerThreads), lds, s, g, src, sort_cap, win_cells);
         return hipGetLastError();
     }
-    // Two workgroups per group, one per direction half, where the rays are sorted and the map is not the workgroup's own:
-    // a launch that cannot fill the chip on its own (a 1 000-scan replay is 125 groups on 256 CUs) runs 11 % shorter
-    // that way (0.088 -> 0.078 ms); when launches of several contexts share the chip the duplicated first pass costs
-    // 4 % of the throughput, so callers that overlap replays switch it off (context option "grid_split")
-    const int split = (!exclusive && sort_cap > 0 && (split_pref > 0 || (split_pref < 0 && (long)groups * L <= 192))) ? 1 : 0;
+    // Two workgroups per group where the rays are sorted and the map is not the workgroup's own - a group whose box fits one
+    // window is shared by beam parity, else one workgroup takes the rays right of the origins' column and one those left of it
+    // (k_grid_update_win): a launch that cannot fill the chip on its own (a 1 000-scan replay is 125 groups on 256 CUs) runs
+    // 11 % shorter that way (0.088 -> 0.078 ms); when launches of several contexts share the chip the duplicated first pass
+    // costs 4 % of the throughput, so callers that overlap replays switch it off (context option "grid_split")
+    const ChipShape chip = chip_shape();
+    const int split = (!exclusive && sort_cap > 0 && (split_pref > 0 || (split_pref < 0 && (long)groups * L <= (3L * chip.cus) / 4))) ? 1 : 0;
     // A launch of at most one workgroup per CU asks for more than half a CU's LDS, so that no CU gets two of its workgroups
     // while others stay empty: the dispatcher does not spread a small grid by itself (stamps, round 4: of 250 workgroups on
     // 256 CUs the slowest took 1.8 x the mean with the same number of cells to walk - it shared its CU with another one).
     size_t lds = win_lds_bytes(group, sort_cap, win_cells);
     const long wgs = (long)(split ? 2 * groups : groups) * L;
-    if (split && wgs <= 256 && lds <= 80 * 1024) lds = 80 * 1024 + 512;
+    // (only where a CU's LDS really is more than twice a workgroup's need, and the larger request is one the device grants)
+    const size_t half_cu = (size_t)(chip.lds_per_cu / 2);
+    if (split && wgs <= chip.cus && lds <= half_cu && half_cu + 512 <= (size_t)chip.lds_per_cu) lds = half_cu + 512;
     if (lds > lds_max) {
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(&k_grid_update_win<Src>), (int)lds);
         if (e != hipSuccess) return e;

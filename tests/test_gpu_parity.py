@@ -909,6 +909,39 @@ def test_icp_clouds_far_from_the_origin_one_pass_products(slam, syn, n, offset):
     assert np.max(np.abs(err - oerr)) < FTOL
 
 
+@pytest.mark.parametrize("max_iter", [1, 2, 30])
+def test_icp_final_transform_offset_million_times_spread(slam, syn, max_iter):
+    """the final T is rebuilt in ONE reduction from the first iteration's source centroid and the last iteration's
+    match centroid (k_icp; the reference calls getTransform(A_original, src_final) with two-pass centroids, icp.py:81,
+    154-160), dropping a term of the order rounding x rounding.  Where that matters most: clouds a MILLION times their
+    spread from the origin (offset / spread >= 1e6: 1e6 ... 4e6 m for a 1 ... 4 m cloud), with a prior applied to the source
+    and with max_iter 1 and 2, where the final transform follows the very first update.  Iteration counts equal; rotation to
+    1e-9; translation to 1e-9 of the offset (a coordinate's own last place there is 2e-10 m; the oracle loses the same digits)."""
+    reps = [syn.make_replay(7, 120, seed=60 + s, stride=5) for s in range(3)]
+    off = np.array([1.0e6, -4.0e6])
+    tars, srcs = [], []
+    rng = np.random.default_rng(61)
+    for rep in reps:
+        pts = np.stack([np.array(co.laser_to_points(r, AMIN, AMAX)) for r in rep.ranges]) * 0.25       # spread ~1-2 m
+        tars.append(pts[:-1] + off[None, :, None])
+        th, tr = rng.normal(0, 0.02, len(pts) - 1), rng.normal(0, 0.03, (len(pts) - 1, 2))
+        src = pts[1:]
+        c, sn = np.cos(th)[:, None], np.sin(th)[:, None]
+        srcs.append(np.stack([c * src[:, 0] - sn * src[:, 1] + tr[:, 0:1], sn * src[:, 0] + c * src[:, 1] + tr[:, 1:2]], axis=1) + off[None, :, None])
+    tars, srcs = np.concatenate(tars), np.concatenate(srcs)
+    T, it, err = slam.icp_batch_host(tars, srcs, max_iter, 0.001)
+    oT, oit, oerr = co.icp_batch(tars, srcs, max_iter, 0.001)
+    assert np.array_equal(it, oit), (it, oit)
+    assert np.max(np.abs(T[:, :2, :2] - oT[:, :2, :2])) < FTOL
+    assert np.max(np.abs(T[:, :2, 2] - oT[:, :2, 2])) < FTOL * np.abs(off).max()
+    assert np.max(np.abs(err - oerr)) < 1e-7                         # (mean distance of points whose coordinates carry 2e-10 m)
+    # the transform maps the source onto the target about as well as the oracle's does (a wrong centroid would show as metres)
+    for b in (0, len(T) - 1):
+        r_dev = T[b, :2, :2] @ srcs[b] + T[b, :2, 2:3]
+        r_ref = oT[b, :2, :2] @ srcs[b] + oT[b, :2, 2:3]
+        assert np.max(np.abs(r_dev - r_ref)) < 1e-4
+
+
 def test_particle_batch_in_chunks_is_identical(slam, syn):
     """Context option "particle_chunks": the batch is cut into chunks whose ray casts run on a second stream behind the
     next chunk's scan matching.  Hypotheses are independent, so poses, transforms, iteration counts and every map must
