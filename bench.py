@@ -75,11 +75,12 @@ AMIN, AMAX = -3.14159, 3.14159
 
 CONFIGS = {
     # name: scans, beams, grid, reso, room_scale, points, seed, lanes
-    # replay: 16 independent replays of the trajectory per slam_replay_dev call on 2 overlapping contexts, 16 scans per ray-cast
+    # replay: 32 independent replays of the trajectory per slam_replay_dev call on 2 overlapping contexts, 16 scans per ray-cast
     # workgroup (profiles/r05_traj_sweep.txt: one 999-pair launch cannot fill the chip - its scan matcher runs 999 pairs in 0.100 ms
-    # alone and in 0.049 ms inside a 16-trajectory launch; rounds 1-4 ran ONE trajectory per call on 4 contexts, kept as
-    # other_configs.lanes4_single_trajectory)
-    "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=2, traj=16, grid_group=16),
+    # alone and in 0.049 ms inside a 16-trajectory launch; 8 / 16 / 32 / 48 trajectories x 2 contexts: 13.5 / 14.6 / 15.0 / 15.2 M
+    # scans/s in the driver's 20-step form, 13.9 / 15.0 / 15.3 / 15.3 M sustained; rounds 1-4 ran ONE trajectory per call on 4
+    # contexts, kept as other_configs.lanes4_single_trajectory)
+    "replay": dict(scans=1000, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=1, lanes=2, traj=32, grid_group=16),
     "dense": dict(scans=1000, beams=1080, grid=2000, reso=0.02, room_scale=2.0, points="f16", seed=3, lanes=4),
     "particles": dict(scans=2, beams=360, grid=400, reso=0.05, room_scale=1.0, points="f64", seed=2, lanes=2),
 }
@@ -133,7 +134,7 @@ def parse():
         # configs[3] (N > 1) names 5k-scan trajectories, configs[1] / [4] a 1k-scan replay
         args.scans = 5000 if (args.gpus > 1 and args.config == "replay") else cfg["scans"]
     if args.traj is None:
-        # about 16 000 scan pairs per scan-matching launch: 16 replays of the 1k-scan trajectory, 3 of a 5k-scan one
+        # about 32 000 scan pairs per scan-matching launch: 32 replays of the 1k-scan trajectory, 6 of a 5k-scan one
         args.traj = max(1, round(cfg["traj"] * 1000 / args.scans)) if "traj" in cfg else 1
     for k in ("beams", "grid", "reso", "room_scale", "points", "lanes"):
         if getattr(args, k) is None:
@@ -320,6 +321,22 @@ def issue_cycles(pmc, insts=None):
 # --------------------------------------------------------------------------------------
 # workloads
 # --------------------------------------------------------------------------------------
+_LANE_STREAMS = {}
+
+
+def lane_stream(torch, local, idx, n_lanes):
+    """The torch stream of lane idx: one lane runs on torch's current stream; several lanes on side streams that are created ONCE
+    per process and shared by every workload that follows (the HIP runtime deals streams to its hardware queues in creation
+    order: a process that had made two dozen streams for the earlier legs ran the 4-lane legs behind them a third slower -
+    lanes of one workload then shared a queue and serialised)."""
+    if n_lanes <= 1:
+        return torch.cuda.current_stream(local)
+    key = (local, idx)
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = torch.cuda.Stream(device=local)
+    return _LANE_STREAMS[key]
+
+
 class ReplayWorkload:
     """configs[1] / [3] / [4]: per lane a DeviceReplay + map + pmap; a step runs on lane slot % lanes."""
     family_kernels = {"icp": "k_icp", "grid": "k_grid_update_win", "compose": "k_pose_compose", "finalize": "k_grid_finalize"}
@@ -338,9 +355,9 @@ class ReplayWorkload:
         class Lane:
             pass
         self.lanes = []
-        for _ in range(max(1, n_lanes)):
+        for li in range(max(1, n_lanes)):
             ln = Lane()
-            ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
+            ln.stream = lane_stream(torch, local, li, n_lanes)
             with torch.cuda.stream(ln.stream):
                 ln.dr = slam.DeviceReplay(ranges, AMIN, AMAX, max_iter=args.max_iter, tolerance=args.tol,
                                           dtype=args.points, device=local, grid_of_traj=np.arange(L) if L > 1 else None)
@@ -480,9 +497,9 @@ class ParticleWorkload:
         class Lane:
             pass
         self.lanes = []
-        for _ in range(max(1, n_lanes)):
+        for li in range(max(1, n_lanes)):
             ln = Lane()
-            ln.stream = torch.cuda.Stream(device=local) if n_lanes > 1 else torch.cuda.current_stream(local)
+            ln.stream = lane_stream(torch, local, li, n_lanes)
             ln.ctx = A.Context(local, ln.stream.cuda_stream)
             # one lane = kernels back to back (the stand-alone durations the rooflines use): no chunks
             ln.ctx.set_option("particle_chunks", args.particle_chunks if n_lanes > 1 or args.lanes == 1 else 1)
@@ -934,12 +951,40 @@ def other_config_summary(args, res, roofline, parity):
     return r
 
 
+def _child_leg(extra):
+    """A secondary measurement in a CHILD process: `python bench.py <extra> --no-cpu-baseline --no-other-configs`, its JSON line
+    condensed like other_config_summary.  For the 4-lane legs: they run a fifth slower at the end of a process that has replayed
+    32 trajectories per call on two other contexts first (dense 1.47-1.56 against 1.65 M scans/s in a process of its own, one
+    trajectory on 4 contexts 9.0 against 11.4 M; two-lane legs are not affected) - the figure a user of `bench.py --config dense`
+    gets is the one of a fresh process.  This process only waits meanwhile (it starts no other program in place of itself)."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-configs"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode or not lines:
+        return {"error": "child rc %d: %s" % (p.returncode, p.stderr[-300:])}
+    d = json.loads(lines[-1])
+    r = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "lanes": d["config"]["lanes"],
+         "trajectories_per_step": d["config"].get("trajectories_per_step"), "workload": d["config"]["workload"],
+         "roofline": {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "lanes", "physical", "hbm_algorithmic",
+                                                        "lds_conflict_cycle_share", "chip", "icp_issue", "stale_pmc", "kernel_ms_per_launch_overlapped") if k in d["roofline"]},
+         "parity": d.get("parity"), "process": "child (python bench.py %s)" % " ".join(extra)}
+    for k_out, k_in in (("single_stream", "single_stream"), ("single_stream_pipelined", "single_stream_pipelined"), ("timing_mask", "timing_mask"), ("instrumented", "instrumented")):
+        if d.get(k_in) is not None:
+            r[k_out] = d[k_in]
+    if d.get("sustained"):
+        r["sustained"] = {k: d["sustained"][k] for k in ("value", "ms_per_step", "steps", "seconds")}
+    return r
+
+
 def _replay_legs(args, env, torch, others):
     """configs[1] again, (a) as rounds 1-4 measured it: ONE trajectory per call on four overlapping contexts, (b) at the W7 launch
     file's scan-matching parameters (SURVEY.md 8d asks for both sets: W7_Dead Reckoning (ICP)/course_agv_slam/launch/icp.launch:10-12
     sets max_iter 10, tolerance 0 - every pair runs exactly ten iterations)."""
-    for name, change in (("lanes4_single_trajectory", dict(traj=1, lanes=4, grid_group=0, steps=48, warmup=5)),
-                         ("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes))):
+    base = ["--max-iter", str(args.max_iter), "--tol", repr(args.tol), "--sustain-seconds", "0.5"] + (["--no-parity"] if args.no_parity else [])
+    others["lanes4_single_trajectory"] = _child_leg(["--config", "replay", "--traj", "1", "--lanes", "4", "--grid-group", "0", "--steps", "48", "--warmup", "5",
+                                                     "--no-single-stream"] + base)
+    for name, change in (("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes)),):
         a4 = argparse.Namespace(**vars(args))
         for k, v in change.items():
             setattr(a4, k, v)
@@ -1016,6 +1061,8 @@ def main():
             os.close(saved)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    for li in range(4):                 # the lanes' streams first, before any other stream of the process (see lane_stream)
+        lane_stream(torch, local, li, 4)
     env = Env(slam, torch, dist, rank, world, local, use_dist)
     cpu = cpu_baseline_first(slam, args, rank) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     res = measure(args, env, want_single=not args.no_single_stream and not use_dist, want_sustained=not use_dist)
@@ -1049,6 +1096,10 @@ def main():
         _replay_legs(args, env, torch, others)
         for name in ("particles", "dense"):
             a2 = config_args(args, name)
+            if name == "dense":                     # four lanes: in a process of its own (_child_leg)
+                others[name] = _child_leg(["--config", "dense", "--max-iter", str(args.max_iter), "--tol", repr(args.tol), "--sustain-seconds", "0.5"] +
+                                          (["--no-parity"] if args.no_parity else []))
+                continue
             try:
                 r2 = measure(a2, env, want_single=True, want_sustained=True)
                 others[name] = other_config_summary(a2, r2, roofline_of(a2, r2), None if args.no_parity else r2["wl"].parity(r2["dev_results"]))

@@ -4,7 +4,7 @@
 # Writes gpurun_out/prof_<tag>_<config>/ (scratch) and the judged summaries into profiles/ via
 # tools/summarize_profiles.py (gpurun merges gpurun_out/ only, so the summaries are also left
 # under gpurun_out/prof_<tag>_<config>/profiles/ - copy them into profiles/ and commit).
-#  1. --kernel-trace --stats of the default bench command of that config (replay: 2 lanes of 16 trajectories,
+#  1. --kernel-trace --stats of the default bench command of that config (replay: 2 lanes of 32 trajectories,
 #     durations include overlap)
 #  2. the same for one lane (kernels back to back: their stand-alone durations)
 #  3. --pmc passes, ONE counter group per run and nothing else enabled (the pool refuses
@@ -20,7 +20,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp || exit 1
 case $CFG in
-  replay) STEPS="--steps 20 --warmup 5"; PSTEPS="--steps 3 --warmup 2";;          # (the driver's form; a step is 16 replays of the trajectory)
+  replay) STEPS="--steps 20 --warmup 5"; PSTEPS="--steps 3 --warmup 2";;          # (the driver's form; a step is 32 replays of the trajectory)
   particles) STEPS="--steps 12 --warmup 3"; PSTEPS="--steps 6 --warmup 6";;   # (PMC figures from the later half of the launches: settled maps)
   *)      STEPS="--steps 12 --warmup 3"; PSTEPS="--steps 3 --warmup 1";;
 esac
