@@ -2193,10 +2193,11 @@ size_t tile_scratch_bytes(long rays, long groups)
     return (size_t)rays * (sizeof(RayRec) + kTileWords * 4 + kTileWords * 2) + (size_t)groups * 16 + 1024;
 }
 
-bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj)
+bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj, int wedges)
 {
-    // one shared map, much larger than a window; a group's ray count must fit the 16-bit tile counters
-    return !got && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= kTileMaxBeams;
+    // maps much larger than a window; a group's ray count must fit the 16-bit counters.  The recorded-walk tiles cast into ONE
+    // shared map; the direction wedges also take a map per trajectory (`got`: dense replays in batches, bench.py --config dense --traj)
+    return (!got || wedges) && !grid_per_traj && (long)g.xw * g.yw > 8L * kWinCells && n <= kTileMaxBeams;
 }
 
 template <class Src>
@@ -2241,15 +2242,16 @@ static hipError_t launch_tiles(const GridDev &g, const Src &src, int L, int scan
 }
 
 template <class Src>
-static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s);
+static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s, const int32_t *got = nullptr);
 
 hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int L, int n_scan, int n, int group,
-                                    void *scratch, hipStream_t s, int wedges)
+                                    void *scratch, hipStream_t s, int wedges, const int32_t *got)
 {
     if (n_scan < 2) return hipSuccess;
     ReplaySource src{ranges, cos_t, sin_t, poses, n_scan, n, (long)n_scan * n, 0, centres};
-    if (wedges) return launch_wedges(g, src, L, n_scan - 1, n, group, scratch, s);
+    if (wedges) return launch_wedges(g, src, L, n_scan - 1, n, group, scratch, s, got);
+    if (got) return hipErrorInvalidValue;                            // (the recorded-walk tiles know one shared map)
     return launch_tiles(g, src, L, n_scan - 1, n, group, scratch, s);
 }
 
@@ -2294,6 +2296,7 @@ struct WedgeScratch {
     int *offs;                 // [groups][kWedgeClasses + 1] class boundaries in the group's list
     uint32_t *cost;            // [groups][kWedgeClasses] cells the class's rays pass (from the length bins: to +-8 cells a ray)
     uint32_t *order;           // [groups * kWedgeClasses] units (group * kWedgeClasses + class), the most cells first
+    const int32_t *got;        // nullable [L]: map of trajectory l (null: every trajectory casts into map 0)
 };
 
 __device__ __forceinline__ int wedge_class(const Ray &r, int ddx, int ddy)
@@ -2324,7 +2327,8 @@ __global__ void __launch_bounds__(1024) k_wedge_sort(GridDev g, Src src, WedgeSc
     const int s0 = blockIdx.x * group_size, cnt = min(group_size, scans - s0);
     const long group = (long)l * groups_per_traj + blockIdx.x;
     const long ray0 = ((long)l * scans + s0) * n;                     // first ray of the group in ends[]
-    uint32_t *pass = g.pass, *hit = g.hit;                            // one shared map (the launcher guarantees it)
+    const size_t map_off = (size_t)(ws.got ? ws.got[l] : 0) * g.xw * g.yw;   // the trajectory's map (one shared map without `got`)
+    uint32_t *pass = g.pass + map_off, *hit = g.hit + map_off;
     if (tid < cnt) {
         src.scan_const(l, s0 + tid, g, sc[tid]);
         ws.orgs[(long)l * scans + s0 + tid] = (uint32_t)(sc[tid].pcx & 0xffff) | ((uint32_t)(sc[tid].pcy & 0xffff) << 16);
@@ -2496,7 +2500,7 @@ __global__ void __launch_bounds__(kWedgeThreads, 2 * kWedgeThreads / 256) k_wedg
     if (lo >= hi) return;
     const bool steep = (cls / kWedgeSlopes) >= 2;
     const int M = wedge_shear(cls);
-    uint32_t *pass = g.pass;
+    uint32_t *pass = g.pass + (size_t)(ws.got ? ws.got[l] : 0) * g.xw * g.yw;
     const unsigned wbase = lds_addr(win);
 
     for (int c0 = lo; c0 < hi; c0 += kWedgeThreads * kWedgeSlots) {     // (one pass unless a class holds more than 2 048 rays)
@@ -2673,7 +2677,7 @@ size_t wedge_scratch_bytes(long rays, long scans, long groups)
 }
 
 template <class Src>
-static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s)
+static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int scans, int n, int group, void *scratch, hipStream_t s, const int32_t *got)
 {
     if (scans < 1) return hipSuccess;
     int G = group > 0 ? group : 16;
@@ -2691,6 +2695,7 @@ static hipError_t launch_wedges(const GridDev &g, const Src &src, int L, int sca
     ws.cost = reinterpret_cast<uint32_t *>(p); p += (size_t)groups * kWedgeClasses * 4;
     ws.order = reinterpret_cast<uint32_t *>(p); p += ((size_t)groups * kWedgeClasses + (size_t)rays / kWedgePartMin + 1) * 4;
     ws.list = reinterpret_cast<unsigned short *>(p);
+    ws.got = got;
     if (g.pmap_live && g.live_dirty) *g.live_dirty = true;
     const size_t lds_a = win_sc_bytes(G) + (size_t)(kWedgeClasses * kWedgeLenBins + kWinMaxGroup) * 4 + (size_t)G * n * 2;
     const size_t lds_b = 64 + (size_t)kWedgeCells * 2 + kLdsGuard;

@@ -930,7 +930,8 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
                        hipStream_t st)
 {
     g->pristine = false;
-    const bool tiles_ok = tiles_apply(g->d, n, got, 0) || ((c->grid_mode == 2 || c->grid_mode == 4) && !got && n <= kTileMaxBeams);
+    const bool tiles_ok = tiles_apply(g->d, n, got, 0, wedges_ok(c, g)) ||
+                          ((c->grid_mode == 2 || c->grid_mode == 4) && (!got || (c->grid_mode == 4 && wedges_ok(c, g))) && n <= kTileMaxBeams);
     if ((c->grid_mode == 1 || c->grid_mode == 2 || c->grid_mode == 4) && tiles_ok) {
         long rays = (long)L * (n_scan - 1) * n, groups = (long)L * (n_scan - 1);
         // the wedges keep 6 bytes per ray (end cell, sorted ray number); the recorded walks of grid_mode 2 ~400
@@ -939,7 +940,7 @@ static int cast_replay(slam_ctx *c, slam_grid *g, const float *ranges, const dou
             if (c->gstream) HIPCHK(hipStreamSynchronize(c->gstream));
             TRY(arena_reserve(c, c->tiles, need));
         }
-        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st, wedges_ok(c, g)));
+        HIPCHK(launch_grid_update_tiles(g->d, ranges, cos_t, sin_t, poses, centres, L, n_scan, n, c->grid_group, c->tiles.base, st, wedges_ok(c, g), got));
         return SLAM_OK;
     }
     if (c->grid_mode != 0) {

@@ -173,10 +173,11 @@ hipError_t launch_grid_update_scans(const GridDev &g, const float *ranges, const
 constexpr int kTileMaxBeams = 8192;      // beams per scan the tiled / wedge paths take (ray numbers inside a group are 16-bit)
 size_t tile_scratch_bytes(long rays, long groups);
 size_t wedge_scratch_bytes(long rays, long scans, long groups);
-bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj);
+bool tiles_apply(const GridDev &g, int n, const int32_t *got, int grid_per_traj, int wedges = 0);
+// got: nullable [L] map of every trajectory (wedges only; the recorded-walk tiles cast into one shared map)
 hipError_t launch_grid_update_tiles(const GridDev &g, const float *ranges, const double *cos_t, const double *sin_t,
                                     const double *poses, const double *centres, int L, int n_scan, int n, int group,
-                                    void *scratch, hipStream_t s, int wedges = 0);
+                                    void *scratch, hipStream_t s, int wedges = 0, const int32_t *got = nullptr);
 hipError_t launch_grid_update_tiles_explicit(const GridDev &g, const double *ox, const double *oy, const double *cx,
                                              const double *cy, int B, int n, int group, void *scratch, hipStream_t s, int wedges = 0);
 hipError_t launch_grid_finalize(const GridDev &g, int g0, int gcount, int8_t *pmap, hipStream_t s);

@@ -60,6 +60,38 @@ def test_config4_dense_1080_f16_2000x2000_tiles(slam, syn):
         assert np.array_equal(r["pass"], dev["pass"]) and np.array_equal(r["hit"], dev["hit"]), mode
 
 
+def test_config4_dense_batch_of_trajectories_into_their_own_maps(slam, syn):
+    """configs[4]'s shape in batches: L = 3 different 1080-beam trajectories per slam_replay_dev call, each into its OWN
+    2000 x 2000 @ 0.02 m map through the direction wedges (round 5: the wedges take a map per trajectory; until then a
+    grid_of_traj sent a large map to the window kernel's scattered atomics).  Every trajectory against the oracle on that
+    trajectory alone (fp16 point buffers for the matcher, float64 points for the map: SURVEY.md 7.3-5), wedges chosen
+    automatically (grid_mode 1) and forced (4); the window (3) and direct atomics (0) give the same maps."""
+    L = 3
+    reps = [syn.make_replay(24, 1080, seed=3 + l, room_scale=2.0, stride=5) for l in range(L)]
+    ranges = np.stack([r.ranges for r in reps])
+    dr = slam.DeviceReplay(ranges, AMIN, AMAX, dtype="f16", grid_of_traj=[2, 0, 1])
+    grid = dr.make_grid(L, 2000, 2000, 0.02)
+    want = {}
+    for mode in (1, 4, 3, 0):
+        dr.ctx.set_option("grid_mode", mode)
+        dr.run()
+        poses, T, it = dr.results()
+        for l, gi in enumerate([2, 0, 1]):
+            r = grid.read(gi, want=("pmap", "pass", "hit"))
+            if mode == 1:
+                og = checks.metric_grid(2000, 2000, 0.02)
+                op, oT, oit, ovis = checks.replay_reference(ranges[l], AMIN, AMAX, og, points="f16")
+                assert np.array_equal(it[l], oit) and np.max(np.abs(poses[l] - op)) < FTOL and np.max(np.abs(T[l] - oT)) < FTOL, l
+                assert np.array_equal(r["pass"], og.pass_cnt) and np.array_equal(r["hit"], og.hit_cnt) and np.array_equal(r["pmap"], og.pmap), l
+                want[gi] = (r, ovis)
+            else:
+                assert np.array_equal(r["pass"], want[gi][0]["pass"]) and np.array_equal(r["hit"], want[gi][0]["hit"]), (mode, l)
+        assert grid.visits() == sum(v[1] for v in want.values()), mode
+    assert not np.array_equal(want[0][0]["pass"], want[1][0]["pass"])          # the maps really are different trajectories'
+    grid.close()
+    dr.ctx.close()
+
+
 # ------------------------------------------------------------------ configs[1] as bench.py runs it since round 5: batches of trajectories
 @pytest.mark.parametrize("group", [0, 16])
 def test_config1_batch_of_8_trajectories_of_1000_scans(slam, syn, group):
