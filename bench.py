@@ -12,8 +12,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 --config selects the BASELINE.json configuration (all print the same JSON shape with "roofline",
 "cpu_baseline" and an in-run "parity" block against the C oracle):
   replay     (default) configs[1]: a 1k-scan replay, 360 beams, ICP.process + Mapping.update per
-             scan into a 400x400 @ 0.05 m grid.  With N > 1: configs[3], one 5k-scan trajectory
-             per GPU (seed 10 + rank), final poses exchanged with one RCCL all_gather.
+             scan into a 400x400 @ 0.05 m grid; a step is --traj = 32 independent replays of that
+             trajectory in one slam_replay_dev call (a map each).  With N > 1: configs[3], one
+             5k-scan trajectory per GPU (seed 10 + rank; 6 replays of it per step), final poses
+             exchanged with one RCCL all_gather.
   particles  configs[2]: 10 000 prior hypotheses of one 360-beam scan pair, one 400x400 @ 0.05 m
              map per particle (maps persist across steps, as in a particle filter).
   dense      configs[4]: 1k-scan replay, 1080 beams, 2000x2000 @ 0.02 m grid, fp16 point buffers.
@@ -27,12 +29,17 @@ path over that batch, inputs (float32 ranges) already resident in HBM:
   particles:      P ICP solves on the prior-perturbed scan -> P pose steps -> P x 360 rays cast
                   into P maps with pmap kept current (no reset: the maps accumulate).
 Unit of `value`: processed scans per second (one ICP.process + one Mapping.update each; for
-particles one per hypothesis), summed over all ranks.  Consecutive steps are independent, so in
-the replay config they are dealt round-robin to --lanes contexts (own stream, map and output
-buffers; default 4) and overlap on the chip; nothing of a step is skipped or shared.
+particles one per hypothesis), summed over all ranks.  Consecutive steps are independent, so
+they are dealt round-robin to --lanes contexts (own stream, maps and output buffers; replay: 2)
+that overlap on the chip; nothing of a step is skipped or shared - every trajectory of a step
+is matched, composed, ray-cast into its own map and finalized, and the in-run parity block
+checks every one of them against the oracle.
 ms_per_step = elapsed / K.  "single_stream" repeats the measurement with ONE lane (kernels back
 to back: per-kernel times there satisfy kernel time <= step time); "sustained" keeps stepping
-the same workload until >= 0.5 s have passed.
+the same workload until >= 3 s (the secondary configurations: 0.5 s) have passed.
+"other_configs": particles, dense, the replay at the W7 launch file's parameters (10, 0) and the
+replay as rounds 1-4 ran it (one trajectory per call on four contexts); the two legs with four
+contexts run in child processes of this one (_child_leg).  The CPU baseline runs first.
 
 Extra objects on the JSON line: "roofline" (dominant kernel; durations from HIP events carried
 by every dispatch on its launch stream), "cpu_baseline" (oracle/slam_oracle.c, the C port of the
@@ -805,7 +812,8 @@ def roofline_of(args, res):
                     "hbm_algorithmic": dict(hbm, note="9 B per cell visit / duration against the 8 TB/s spec: bytes the LDS window absorbs - HBM sees `traffic`"),
                     "lds_conflict_cycle_share": pmc.get("lds_conflict_cycle_share"),
                     "note": "achieved = in-bounds cell visits per launch / stand-alone duration of the whole launch (walk AND its set-up, sort, zero, flush phases); "
-                            "peak = ds_add_u32 rate of 256 CUs for the walk's address pattern (tools/ubench_issue.hip: 5.95 per cycle per CU with 16 waves)"}
+                            "peak = ds_add_u32 rate of 256 CUs for the walk's address pattern (tools/ubench_issue.hip: 5.95 per cycle per CU with 16 waves); "
+                            "with two workgroups per CU the walk's vector issue is level with its LDS atomics (profiles/r05_dropped_experiments.txt #6, DESIGN.md K4a)"}
     else:
         roofline = dict(hbm, kernel=kname, bound="hbm", traffic=traffic)
         if traffic and alone_ms:
