@@ -453,9 +453,9 @@ struct PolarGeo {
 template <int UNROLL, bool PROBE>
 __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n_tar, double sx, double sy, int seed,
                                          bool active, const PolarGeo &geo, int wmax, double &best_d2, int &best_j, bool &big,
-                                         bool &amb)
+                                         bool &amb, unsigned long long &ambm)
 {
-    seed = min(max(seed, 0), n_tar - 1);
+    // (seed is a valid target index: the same beam clamped to the target's size before the first iteration, a match after it)
     const float fsx = (float)sx, fsy = (float)sy;
     const float rs2 = fsx * fsx + fsy * fsy;
     int lo, hi;
@@ -554,17 +554,25 @@ __device__ __forceinline__ void nn_polar(const double2 *__restrict__ tarP, int n
     // (the scan may close on itself with its last beam up to half a beam spacing PAST its first - polar_probe admits
     // that much: wrapped beam m lies at least n - 1 + m - 1/2 spacings above beam 0's index, so it belongs to the
     // window when m <= hi - (n - 1) + 1, and likewise below)
-    const int e0 = hi >= n_tar - 2 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;        // [0, e0]
-    const int s2 = lo <= 1 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;               // [s2, n_tar - 1]
+    // [0, e0] = [0, min(hi - (n - 1) + 1, m0 - 1)] when hi >= n - 2, and [s2, n - 1] = [max(n - 1 + lo - 1, m1 + 1), n - 1] when
+    // lo <= 1; non-empty iff (hi >= n - 2 and lo >= 1) resp. (lo <= 1 and hi <= n - 2).  Rare: ONE wave-uniform test on lo
+    // and hi, and the two ranges are formed only behind it (they were 10 vector instructions per query and iteration).
     Best b;
     b.start();
-    const bool wraps = __any(go && (e0 >= 0 || s2 < n_tar));        // (rare: one wave-uniform test instead of two empty loops)
-    if (wraps) scan(go ? 0 : 1, go ? e0 : 0, b);
+    const bool wraps = __any(go && ((hi >= n_tar - 2 && lo >= 1) || (lo <= 1 && hi <= n_tar - 2)));
+    if (wraps) {
+        const int e0 = hi >= n_tar - 2 ? min(hi - (n_tar - 1) + 1, m0 - 1) : -1;    // [0, e0]
+        scan(go ? 0 : 1, go ? e0 : 0, b);
+    }
     scan(go ? m0 : 1, go ? m1 : 0, b);
-    if (wraps) scan(go ? s2 : 1, go ? n_tar - 1 : 0, b);
+    if (wraps) {
+        const int s2 = lo <= 1 ? max(n_tar - 1 + lo - 1, m1 + 1) : n_tar;           // [s2, n_tar - 1]
+        scan(go ? s2 : 1, go ? n_tar - 1 : 0, b);
+    }
     best_d2 = b.d2;
     best_j = b.j;
     amb = go && b.amb();
+    ambm = b.ambm;                       // the same as a wave-wide mask (a lane that is not `go` compared nothing: its bit is never set)
 }
 
 // ---------------------------------------------------------------------------------
@@ -640,7 +648,8 @@ __device__ __forceinline__ void nn_listed(const double2 *__restrict__ tarP, int 
         double d2;
         int j;
         bool big, amb;
-        nn_polar<UNROLL, true>(tarP, n_tar, qp.x, qp.y, qseed[act ? e : nq - 1], act, geo, kPolarMaxListed, d2, j, big, amb);
+        unsigned long long ambm;
+        nn_polar<UNROLL, true>(tarP, n_tar, qp.x, qp.y, qseed[act ? e : nq - 1], act, geo, kPolarMaxListed, d2, j, big, amb, ambm);
         if (act && !big) qlist[e] = make_double2(d2, __hiloint2double(0, j | (amb ? (int)0x80000000 : 0)));
         unsigned long long left = __ballot(big);
         while (left != 0ull) {                                       // four of the remaining queries, one per row
@@ -873,7 +882,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
         }
         sx[q] = ax[q] = x;
         sy[q] = ay[q] = y;
-        seed[q] = i;                             // first guess: the same beam index
+        seed[q] = min(i, n_tar - 1);             // first guess: the same beam index
     }
     bool src_differs = false;
     {
@@ -920,7 +929,8 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     ISTAMP(14);
     double pre_error = 0.0, mean_error = 0.0, pcx = 0.0, pcy = 0.0, ca0x = 0.0, ca0y = 0.0;   // (ca0: centroid of the source before it moves)
     int iters = 0, par = 0;
-    bool amb_any = false;
+    unsigned long long amb_mask = 0ull;   // lanes of this wave that saw a best undercut its predecessor by less than a class of equal distances:
+                                          // kept as a wave-wide mask in scalar registers (a per-lane flag cost four vector instructions a query)
     // one iteration; FIRST: the instance for iteration 0 (two reductions as the reference; the only one that lists queries
     // for nn_listed), the loop behind it takes the one-pass form; returns true when the solve has converged (icp.py:76-77)
     auto iterate = [&](auto first_tag, const int it) __attribute__((always_inline)) -> bool {
@@ -933,15 +943,17 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             double d2; int j;
-            bool amb = false;
             slot[q] = -1;
             if (EXACT) {
                 const NNHit h = nn_exact(has_p ? tarP : tarL, !has_p, ok[q] ? n_tar : 0, sx[q], sy[q]);
                 d2 = h.d2; j = h.j;
             } else if (pg.inv_db > 0.0f) {                           // wave-uniform: the target is a scan
-                bool big;
+                bool big, amb_lane;
+                unsigned long long am;
                 nn_polar<UNROLL, false>(tarP, n_tar, sx[q], sy[q], seed[q], ok[q], pg, team_it ? kPolarMaxFirst : kPolarMax, d2, j,
-                                        big, amb);                   // icp.py:67
+                                        big, amb_lane, am);          // icp.py:67
+                (void)amb_lane;
+                amb_mask |= am;
                 if (FIRST && team_it) {
                     const unsigned long long bm = __ballot(big);
                     if (bm != 0ull) {
@@ -968,12 +980,13 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
                     nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, big, d2b, jb, ambb);
                     d2 = big ? d2b : d2;
                     j = big ? jb : j;
-                    amb = big ? ambb : amb;
+                    amb_mask |= __ballot(big && ambb);
                 }
             } else {
-                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, ok[q], d2, j, amb);   // icp.py:67
-            }
-            amb_any |= amb;                                          // -> the pair is re-done (icp_pair<EXACT>)
+                bool ambs;
+                nn_search(tarL, boxes, boxes4, nblocks, n_tar, sx[q], sy[q], seed[q], FIRST, ok[q], d2, j, ambs);   // icp.py:67
+                amb_mask |= __ballot(ambs);
+            }                                                        // (amb_mask != 0 -> the pair is re-done: icp_pair<EXACT>)
             seed[q] = j;                                             // next iteration's guess
             double2 m = has_p ? tarP[j] : tarL[tslot(j)];
             mx[q] = m.x; my[q] = m.y;
@@ -985,15 +998,17 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < QPT; ++q) {
+                bool flagged = false;
                 if (slot[q] >= 0) {
                     const double2 rs = qlist[slot[q]];
                     const int jf = __double2loint(rs.y), j = jf & 0x7fffffff;
-                    amb_any |= jf < 0;
+                    flagged = jf < 0;
                     seed[q] = j;
                     const double2 m = tarP[j];
                     mx[q] = m.x; my[q] = m.y;
                     dq[q] = (rs.x < INFINITY) ? sqrt(rs.x) : 0.0;
                 }
+                amb_mask |= __ballot(flagged);
             }
         }
         // every source point matched to ONE target point (same coordinates)?  see "collapsed sets" above.  Every wave
@@ -1080,7 +1095,8 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
                 if (ok[q]) {
                     const double dax = sx[q] - pcx, day = sy[q] - pcy, dbx = mx[q] - pcx, dby = my[q] - pcy;
                     u[0] += dax; u[1] += day; u[2] += dbx; u[3] += dby; u[4] += dq[q];
-                    u[5] += dbx * dax + dby * day; u[6] += dby * dax - dbx * day;
+                    // (fused: two instructions a sum instead of four - these sums are this kernel's own form of W anyway, K2)
+                    u[5] = fma(dbx, dax, fma(dby, day, u[5])); u[6] = fma(dby, dax, fma(-dbx, day, u[6]));
                 }
             }
             ISTAMP(1);
@@ -1146,7 +1162,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
 
     // (a pair in which some lane saw a best undercut its predecessor by less than a class of equal distances is
     // re-done: the flag travels through LDS, behind the barriers of the sums below)
-    if (!EXACT && amb_any) geo[5] = 1u;
+    if (!EXACT && amb_mask != 0ull) geo[5] = 1u;
     // final T = getTransform(A_original, src_final) (icp.py:81).  ONE reduction when an iteration has run: the originals'
     // centroid c_A is the first iteration's source centroid (the same sums in the same order - the source had not moved yet),
     // and the last update put the source's centroid on p = (pcx, pcy) up to rounding, so with S = sum (s - p)
@@ -1222,7 +1238,7 @@ __device__ __forceinline__ bool icp_pair(const IcpArgs &a, const int b, char *sm
     ISTAMP(5);
     ISTAMP_END(iters);
     lds_guard_check(guard, a.status);
-    return !EXACT && (nwaves > 1 ? geo[5] != 0u : __any(amb_any));
+    return !EXACT && (nwaves > 1 ? geo[5] != 0u : amb_mask != 0ull);
 }
 
 // k_icp: one workgroup per pair.  None of the pairs of noisy scans and a few per cent of those with quantised ranges

@@ -320,7 +320,15 @@ def issue_cycles(pmc, insts=None):
     cyc = ((n["f64_arith"] + n["f64_cmp_minmax_est"]) * ISSUE_COST["f64"] + (n["cvt"] + n["dpp_lane_est"]) * ISSUE_COST["quarter"] +
            n["f64_trans"] * ISSUE_COST["trans_f64"] + n["trans_f32"] * ISSUE_COST["trans_f32"] + rest * ISSUE_COST["simple"])
     n["simple"] = rest
+    counted = n["f64_arith"] + n["f64_trans"] + n["cvt"] + n["trans_f32"]
+    est = n["f64_cmp_minmax_est"] + n["dpp_lane_est"]
     return cyc, {"instructions": n, "cycles_per_instruction": cyc / insts, "cost_cycles": ISSUE_COST,
+                 # which share of the launch's instructions the hardware counted by class, which entered by their static share of
+                 # the ISA (priced at the float64 / quarter-rate cost), and the rest at the plain 32-bit cost; the PMC-side check of
+                 # the resulting fraction is roofline.valu_busy_frac_pmc (SQ_ACTIVE_INST_VALU x 4 cycles / the launch's SIMD cycles)
+                 "counted_by_class_share": counted / insts, "estimated_from_static_isa_share": est / insts, "plain_32bit_share": rest / insts,
+                 "cycles_if_estimated_classes_were_plain": (cyc - (n["f64_cmp_minmax_est"] * (ISSUE_COST["f64"] - ISSUE_COST["simple"]) +
+                                                                   n["dpp_lane_est"] * (ISSUE_COST["quarter"] - ISSUE_COST["simple"]))) / insts,
                  "counters": hw.get("source"), "costs": "profiles/r04_ubench_issue.txt (tools/ubench_issue.hip)",
                  "estimated": "float64 compares / min / max, DPP / lane exchanges and selects have no hardware counter: static share of the kernel's ISA relative to its float64 arithmetic"}
 
