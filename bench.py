@@ -967,7 +967,7 @@ def other_config_summary(args, res, roofline, parity):
     return r
 
 
-def _child_leg(extra):
+def _child_leg(extra, roofline=True):
     """A secondary measurement in a CHILD process: `python bench.py <extra> --no-cpu-baseline --no-other-configs`, its JSON line
     condensed like other_config_summary.  For the 4-lane legs: they run a fifth slower at the end of a process that has replayed
     32 trajectories per call on two other contexts first (dense 1.47-1.56 against 1.65 M scans/s in a process of its own, one
@@ -985,6 +985,8 @@ def _child_leg(extra):
          "roofline": {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "lanes", "physical", "hbm_algorithmic",
                                                         "lds_conflict_cycle_share", "chip", "icp_issue", "stale_pmc", "kernel_ms_per_launch_overlapped") if k in d["roofline"]},
          "parity": d.get("parity"), "process": "child (python bench.py %s)" % " ".join(extra)}
+    if not roofline:            # (a leg without the one-lane repeat has no stand-alone durations to price a roofline with)
+        r["kernel_ms_per_launch_overlapped"] = r.pop("roofline").get("kernel_ms_per_launch_overlapped")
     for k_out, k_in in (("single_stream", "single_stream"), ("single_stream_pipelined", "single_stream_pipelined"), ("timing_mask", "timing_mask"), ("instrumented", "instrumented")):
         if d.get(k_in) is not None:
             r[k_out] = d[k_in]
@@ -999,7 +1001,7 @@ def _replay_legs(args, env, torch, others):
     sets max_iter 10, tolerance 0 - every pair runs exactly ten iterations)."""
     base = ["--max-iter", str(args.max_iter), "--tol", repr(args.tol), "--sustain-seconds", "0.5"] + (["--no-parity"] if args.no_parity else [])
     others["lanes4_single_trajectory"] = _child_leg(["--config", "replay", "--traj", "1", "--lanes", "4", "--grid-group", "0", "--steps", "48", "--warmup", "5",
-                                                     "--no-single-stream"] + base)
+                                                     "--no-single-stream"] + base, roofline=False)
     for name, change in (("replay_w7_params", dict(max_iter=10, tol=0.0, steps=12 - 12 % max(args.lanes, 1) or args.lanes)),):
         a4 = argparse.Namespace(**vars(args))
         for k, v in change.items():
