@@ -10,6 +10,7 @@ from oracle import c_oracle as co
 
 pytestmark = pytest.mark.gpu
 FTOL = 1e-9
+AMIN, AMAX = -3.14159, 3.14159
 import os
 
 # SLAM_HYP_EXAMPLES=1000 turns the suite into a soak run
@@ -272,3 +273,42 @@ def test_scan_matcher_random_streams_both_first_iteration_paths(slam):
         assert np.array_equal(it0, it1) and np.array_equal(T0, T1), (case, n, kind)
         assert np.array_equal(it0, oit), (case, n, kind)
         assert np.nanmax(np.abs(p0 - oposes)) < FTOL, (case, n, kind)
+
+
+@settings(**{**SET, "max_examples": max(30, SET["max_examples"] // 2)})
+@given(seed=st.integers(0, 2**31 - 1), L=st.integers(1, 6), scans=st.integers(2, 40), n=st.integers(8, 200), maps=st.integers(1, 4),
+       group=st.sampled_from([0, 1, 5, 16]), split=st.sampled_from([-1, 0, 1]), pipeline=st.sampled_from([0, 1]),
+       grid=st.sampled_from([(200, 0.1), (400, 0.05), (96, 0.25)]))
+def test_batched_trajectories_random_routing(slam, syn, seed, L, scans, n, maps, group, split, pipeline, grid):
+    """What bench.py's step is made of since round 5, at random shapes: L trajectories of different scans per slam_replay_dev
+    call, routed to `maps` maps by a random grid_of_traj (several trajectories may SHARE a map: integer evidence adds up,
+    mapping.py:42-45), different start poses, any scans-per-workgroup / split / pipeline setting, maps reset by the call
+    itself.  Every trajectory's poses, transforms and iteration counts against the oracle on that trajectory alone, every
+    map's counters and pmap against the oracle maps that received the same trajectories, visits in total."""
+    rng = np.random.default_rng(seed)
+    reps = [syn.make_replay(scans, n, seed=int(rng.integers(0, 10**6)), stride=int(rng.integers(1, 6))) for _ in range(L)]
+    ranges = np.stack([r.ranges for r in reps])
+    got = rng.integers(0, maps, size=L)
+    p0 = rng.normal(0, [0.4, 0.4, 0.8], size=(L, 3))
+    xw, reso = grid
+    dr = slam.DeviceReplay(ranges, AMIN, AMAX, pose0=p0, grid_of_traj=got)
+    g = dr.make_grid(maps, xw, xw, reso)
+    for k, v in (("grid_group", group), ("grid_split", split), ("pipeline", pipeline)):
+        dr.ctx.set_option(k, v)
+    dr.run()
+    dr.run()                                                     # (the second pass starts from maps the call itself reset)
+    poses, T, it = dr.results()
+    s = 1.0 / reso
+    ogs = [co.Grid(xw, xw, float(round(s)), xw / (2.0 * round(s)), xw / (2.0 * round(s))) for _ in range(maps)]
+    total = 0
+    for l in range(L):
+        op, oT, oit, ovis = co.replay(ranges[l], AMIN, AMAX, ogs[got[l]], pose0=tuple(p0[l]))
+        assert np.array_equal(it[l], oit), l
+        assert np.max(np.abs(poses[l] - op)) < FTOL and np.max(np.abs(T[l] - oT)) < FTOL, l
+        total += ovis
+    for m in range(maps):
+        r = g.read(m, want=("pmap", "pass", "hit"))
+        assert np.array_equal(r["pass"], ogs[m].pass_cnt) and np.array_equal(r["hit"], ogs[m].hit_cnt) and np.array_equal(r["pmap"], ogs[m].pmap), m
+    assert g.visits() == total
+    g.close()
+    dr.ctx.close()
