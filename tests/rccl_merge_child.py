@@ -73,12 +73,23 @@ def main():
     torch.cuda.synchronize()
     out["unordered_read_mismatches"] = int(early.item())
 
-    # 1. asynchronous run, merge immediately behind it, read on torch's stream
-    dr2.run()                                                     # (resets the maps first: option replay_reset)
-    slam.dist.all_reduce_grid(g2)
-    p, hh = g2.counters_torch()
-    bad = (p.sum(0).to(torch.int64) - ref_p).abs().sum() + (hh.sum(0).to(torch.int64) - ref_h).abs().sum()
-    out["merged_counter_mismatches"] = int(bad.item())
+    # 1. asynchronous run, merge immediately behind it, read on torch's stream - with everything on the context's stream and
+    #    with the "pipeline" option (pose composition and ray cast on two further streams of the context, which the ordering
+    #    call has to join first)
+    out["merged_counter_mismatches"] = 0
+    for pipeline in (0, 1):
+        dr2.ctx.set_option("pipeline", pipeline)
+        dr2.run()                                                 # (resets the maps first: option replay_reset)
+        slam.dist.all_reduce_grid(g2)
+        p, hh = g2.counters_torch()
+        bad = (p.sum(0).to(torch.int64) - ref_p).abs().sum() + (hh.sum(0).to(torch.int64) - ref_h).abs().sum()
+        out["merged_counter_mismatches"] += int(bad.item())
+        dr2.run()                                                 # the next update right behind the merge: ordered behind it (direction 1)
+        dr2.ctx.synchronize()
+        torch.cuda.synchronize()
+        again = (p.sum(0).to(torch.int64) - ref_p).abs().sum() + (hh.sum(0).to(torch.int64) - ref_h).abs().sum()
+        out["merged_counter_mismatches"] += int(again.item())
+    dr2.ctx.set_option("pipeline", 0)
     out["cells_touched"] = int((ref_p + ref_h > 0).sum().item())
 
     # 2. the context waits for torch's stream
